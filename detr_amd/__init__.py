@@ -1,0 +1,12 @@
+"""detr_amd -- the DETR-family bipartite-matching path on MI355X (gfx950).
+
+``HungarianMatcher`` is a drop-in for the reference's ``models.matcher.HungarianMatcher``;
+the work is done by two hand-written HIP kernels in ``libdetr_match.so`` (C ABI declared in
+``include/detr_match.h``).  Importing the package fails if that library has not been built.
+"""
+from ._lib import LIB_PATH, lib  # noqa: F401  (fails loudly when the extension is missing)
+from .matcher import HungarianMatcher, PackedTargets  # noqa: F401
+from .lsap import batched_linear_sum_assignment  # noqa: F401
+from . import dist, synth  # noqa: F401
+
+__all__ = ["HungarianMatcher", "PackedTargets", "batched_linear_sum_assignment", "dist", "synth", "LIB_PATH"]

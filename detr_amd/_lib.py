@@ -1,0 +1,75 @@
+"""ctypes binding of libdetr_match.so (declared in include/detr_match.h).
+
+There is no fallback: if the shared object is missing, importing this module
+raises, and so does every matcher call.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libdetr_match.so")
+
+ABI_VERSION = 1
+MAX_SETS_PER_LAUNCH = 16
+
+OK, E_INVALID_ARG, E_LAUNCH, E_UNSUPPORTED = 0, -1, -2, -3
+ST_LABEL_RANGE, ST_DEGENERATE_BOX, ST_INVALID_COST, ST_INFEASIBLE = 1, 2, 4, 8
+
+
+class DmSet(ctypes.Structure):
+    _fields_ = [("logits", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
+                ("cost_off", ctypes.c_int64), ("out_off", ctypes.c_int64),
+                ("Q", ctypes.c_int32), ("q_stride", ctypes.c_int32)]
+
+
+class DmParams(ctypes.Structure):
+    _fields_ = [("cls_mode", ctypes.c_int32), ("w_class", ctypes.c_float), ("w_bbox", ctypes.c_float),
+                ("w_giou", ctypes.c_float), ("focal_alpha", ctypes.c_float), ("focal_gamma", ctypes.c_float)]
+
+
+#: every symbol include/detr_match.h declares
+EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
+           "dm_cost_f32", "dm_lap_f32", "dm_match_f32"]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension with `python -m detr_amd.build` "
+            "(there is no CPU fallback for the matching path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
+    lib.dm_abi_version.restype = ctypes.c_int
+    lib.dm_abi_version.argtypes = []
+    lib.dm_strerror.restype = ctypes.c_char_p
+    lib.dm_strerror.argtypes = [ctypes.c_int]
+    lib.dm_last_hip_error.restype = ctypes.c_char_p
+    lib.dm_last_hip_error.argtypes = []
+    lib.dm_device_count.restype = ctypes.c_int
+    lib.dm_device_count.argtypes = []
+    setp, prmp = ctypes.POINTER(DmSet), ctypes.POINTER(DmParams)
+    lib.dm_cost_f32.restype = ctypes.c_int
+    lib.dm_cost_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, i32, prmp, vp, vp, vp]
+    lib.dm_lap_f32.restype = ctypes.c_int
+    lib.dm_lap_f32.argtypes = [setp, i32, i32, vp, vp, vp, i32, i64p, i64p, vp, vp]
+    lib.dm_match_f32.restype = ctypes.c_int
+    lib.dm_match_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, prmp, vp, i64p, i64p, vp, vp]
+    lib.dm_debug_force_generic_lap.restype = None
+    lib.dm_debug_force_generic_lap.argtypes = [ctypes.c_int]
+    if lib.dm_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.dm_abi_version()} != {ABI_VERSION}; rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc == OK:
+        return
+    msg = lib.dm_strerror(rc).decode()
+    if rc == E_LAUNCH:
+        msg += ": " + lib.dm_last_hip_error().decode()
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")

@@ -1,0 +1,45 @@
+"""Builds libdetr_match.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m detr_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the
+resulting shared object travels with the tree to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libdetr_match.so")
+SOURCES = ["cost_kernel.hip", "lap_kernel.hip", "abi.hip"]
+HEADERS = [os.path.join(CSRC, "dm_common.h"), os.path.join(ROOT, "include", "detr_match.h")]
+# -ffp-contract=off: every fp32 operation of the cost is rounded separately, as in the
+# reference's elementwise torch ops (hipcc would otherwise fuse a*b+c into an fma).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    built = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,82 @@
+// Shared pieces of the gfx950 matching kernels: kernel-argument structs and wave64
+// cross-lane reductions built on DPP.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "detr_match.h"
+
+// The sets of one launch travel by value in the kernel-argument segment: no descriptor
+// table in device memory, nothing to upload per call.
+struct DmSetArray {
+    DmSet s[DM_MAX_SETS_PER_LAUNCH];
+};
+
+namespace dm {
+
+constexpr int WAVE = 64;
+
+// DPP controls (GCN3/GFX9 encoding, all valid on gfx950)
+constexpr int DPP_QUAD_SWAP1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_SWAP2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_SHR4 = 0x114;
+constexpr int DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int v)
+{
+    // lanes without a source (or masked rows) keep their own value: harmless for min/max
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    int lo = dpp_move<CTRL, ROW_MASK>(__double2loint(v));
+    int hi = dpp_move<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// Minimum of a double over the 64 lanes of the wave, returned in every lane (wave-uniform).
+// Values must not be NaN.
+__device__ __forceinline__ double wave_min_f64(double x)
+{
+    x = fmin(x, dpp_move<DPP_QUAD_SWAP1, 0xF>(x));
+    x = fmin(x, dpp_move<DPP_QUAD_SWAP2, 0xF>(x));
+    x = fmin(x, dpp_move<DPP_ROW_SHR4, 0xF>(x));
+    x = fmin(x, dpp_move<DPP_ROW_SHR8, 0xF>(x));      // lanes 12..15 of each row: row minimum
+    x = fmin(x, dpp_move<DPP_ROW_BCAST15, 0xA>(x));   // lane 31: rows 0-1, lane 63: rows 2-3
+    x = fmin(x, dpp_move<DPP_ROW_BCAST31, 0xC>(x));   // lane 63: all four rows
+    int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Maximum of an unsigned over the wave, wave-uniform result.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x)
+{
+    int v = (int)x;
+    auto mx = [](int a, int b) { return (int)max((unsigned)a, (unsigned)b); };
+    v = mx(v, dpp_move<DPP_QUAD_SWAP1, 0xF>(v));
+    v = mx(v, dpp_move<DPP_QUAD_SWAP2, 0xF>(v));
+    v = mx(v, dpp_move<DPP_ROW_SHR4, 0xF>(v));
+    v = mx(v, dpp_move<DPP_ROW_SHR8, 0xF>(v));
+    v = mx(v, dpp_move<DPP_ROW_BCAST15, 0xA>(v));
+    v = mx(v, dpp_move<DPP_ROW_BCAST31, 0xC>(v));
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+
+__device__ __forceinline__ int readlane_i32(int v, int lane)
+{
+    return __builtin_amdgcn_readlane(v, lane);
+}
+
+__device__ __forceinline__ void raise_status(int32_t *status, int bits)
+{
+    atomicOr(status, bits);
+}
+
+}  // namespace dm

@@ -1,0 +1,42 @@
+"""Data-parallel glue for the matching path: one process per GPU, images sharded by rank.
+
+Matching needs no exchange between ranks -- every (output set, image) problem depends on
+that image alone (/root/reference/models/matcher.py:94 uses block i only).  The one
+collective of the step is the normalisation constant of the losses: the reference
+divides by the local ``max(len(idx[0]), 1)`` (/root/reference/models/detr/loss.py:100,119);
+under data parallelism the matched-box counts of all output sets are summed over ranks in
+a single all-reduce (RCCL over xGMI when the backend is "nccl") and divided by the world
+size, so that averaging gradients over ranks normalises by the global count.
+"""
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def matched_box_counts(target_sizes: Sequence[int], set_queries: Sequence[int]) -> List[int]:
+    """Pairs the matcher returns per output set on this rank: sum_b min(Q_s, T_b).
+
+    Known from tensor shapes alone, i.e. before any kernel has run."""
+    return [sum(min(q, t) for t in target_sizes) for q in set_queries]
+
+
+def shard_range(n_images: int, rank: int, world_size: int):
+    """Contiguous image range [lo, hi) owned by ``rank``."""
+    base, extra = divmod(n_images, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> torch.Tensor:
+    """[S] float32 tensor on ``device``: clamp(sum over ranks / world_size, min=1).
+
+    One collective for all S output sets.  It can be issued right after the targets are
+    packed; it does not depend on the assignment."""
+    counts = torch.tensor(list(local_counts), dtype=torch.float32, device=device)
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        if world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+            counts = counts / world
+    return counts.clamp_(min=1.0)

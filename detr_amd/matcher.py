@@ -1,0 +1,244 @@
+"""Drop-in HungarianMatcher backed by the gfx950 kernels in libdetr_match.so.
+
+Same constructor, call convention and return value as the reference module
+(/root/reference/models/matcher.py:13-95): ``matcher(outputs, targets)`` returns a
+list of ``(index_i, index_j)`` CPU int64 tensors, one per image, with
+``len == min(num_queries, num_targets)``.
+
+On top of that, ``match_many`` matches every Hungarian-matched output set of a
+training step (the decoder layers the criteria loop over, e.g.
+/root/reference/models/dino_detr/loss.py:165-199, plus the two-stage encoder head)
+in one cost launch, one assignment launch and one device-to-host copy.
+
+There is no CPU path: inputs must live on a GPU and the HIP library must be built.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DmParams, DmSet, lib
+
+Indices = List[Tuple[torch.Tensor, torch.Tensor]]
+
+
+class PackedTargets:
+    """The targets of one batch, packed once and shared by every output set of the step.
+
+    labels [M] int64, boxes [M, 4] float32 (cxcywh), both on the device; per-image
+    offsets and the largest-first processing order travel in one small upload.
+    """
+
+    def __init__(self, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device):
+        self.sizes = [int(t["boxes"].shape[0]) for t in targets]
+        self.batch = len(self.sizes)
+        for t, n in zip(targets, self.sizes):
+            if int(t["labels"].shape[0]) != n:
+                raise ValueError("a target's labels and boxes differ in length")
+        self.total = sum(self.sizes)
+        self.max_t = max(self.sizes) if self.sizes else 0
+        self.device = device
+        if self.total > 0:
+            labels = torch.cat([t["labels"] for t in targets])
+            boxes = torch.cat([t["boxes"] for t in targets])
+            if boxes.device != device or labels.device != device:
+                raise ValueError("targets and predictions must be on the same device")
+            if boxes.dtype != torch.float32:
+                raise RuntimeError(f"target boxes must be float32, got {boxes.dtype}")
+            self.labels = labels.to(torch.int64).contiguous()
+            self.boxes = boxes.reshape(-1, 4).contiguous()
+        else:
+            self.labels = torch.zeros(1, dtype=torch.int64, device=device)
+            self.boxes = torch.zeros(1, 4, dtype=torch.float32, device=device)
+        meta = np.empty(2 * self.batch + 1, dtype=np.int32)
+        meta[0] = 0
+        np.cumsum(self.sizes, out=meta[1:self.batch + 1])
+        # heavy images first: the assignment kernel's tail is set by the largest T
+        meta[self.batch + 1:] = np.argsort(-np.asarray(self.sizes, dtype=np.int64), kind="stable")
+        self.offsets_host = meta[:self.batch + 1]
+        staged = torch.empty(meta.shape[0], dtype=torch.int32, pin_memory=True)
+        staged.numpy()[:] = meta
+        self.meta = staged.to(device, non_blocking=True)
+
+    @property
+    def offsets_ptr(self) -> int:
+        return self.meta.data_ptr()
+
+    @property
+    def order_ptr(self) -> int:
+        return self.meta.data_ptr() + 4 * (self.batch + 1)
+
+
+def _raise_for_status(bits: int):
+    # same precedence as the reference: the class-cost gather (IndexError) runs before the
+    # box asserts (AssertionError), which run before scipy (ValueError)
+    if bits & _lib.ST_LABEL_RANGE:
+        raise IndexError("target label out of range for the logits' class dimension")
+    if bits & _lib.ST_DEGENERATE_BOX:
+        raise AssertionError("degenerate box (x1 < x0, y1 < y0 or NaN) in predictions or targets")
+    if bits & _lib.ST_INVALID_COST:
+        raise ValueError("matrix contains invalid numeric entries")
+    if bits & _lib.ST_INFEASIBLE:
+        raise ValueError("cost matrix is infeasible")
+
+
+class HungarianMatcher(torch.nn.Module):
+    """Assignment between targets and predictions (reference: models/matcher.py:13-36)."""
+
+    def __init__(self, cls_loss: str = "ce", cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1,
+                 focal_alpha: float = 0.25, focal_gamma: float = 2.0):
+        super().__init__()
+        self.cost_class = cost_class
+        self.cost_bbox = cost_bbox
+        self.cost_giou = cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        self.cls_loss = cls_loss
+        self.focal_alpha = focal_alpha
+        self.focal_gamma = focal_gamma
+        self.last_status = None
+
+    def _params(self) -> DmParams:
+        return DmParams(0 if self.cls_loss == "ce" else 1, float(self.cost_class), float(self.cost_bbox),
+                        float(self.cost_giou), float(self.focal_alpha), float(self.focal_gamma))
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict[str, torch.Tensor], targets) -> Indices:
+        """One output set; same contract as the reference's forward (matcher.py:38-95)."""
+        return self.match_many([outputs], targets)[0]
+
+    @staticmethod
+    def _prepare_sets(outputs_list, batch: int):
+        logits0 = outputs_list[0]["pred_logits"]
+        device, C = logits0.device, int(logits0.shape[-1])
+        if device.type != "cuda":
+            raise RuntimeError("detr_amd.HungarianMatcher runs on the GPU only (got tensors on %s)" % device)
+        keep, dims = [], []
+        for out in outputs_list:
+            logits, boxes = out["pred_logits"], out["pred_boxes"]
+            if logits.dim() != 3 or boxes.dim() != 3 or boxes.shape[-1] != 4:
+                raise ValueError("pred_logits must be [B, Q, C] and pred_boxes [B, Q, 4]")
+            if logits.shape[0] != batch or boxes.shape[0] != batch or logits.shape[1] != boxes.shape[1]:
+                raise ValueError("pred_logits / pred_boxes / targets disagree on batch size or query count")
+            if int(logits.shape[-1]) != C:
+                raise ValueError("all output sets of one call must share the class dimension")
+            if logits.dtype != torch.float32 or boxes.dtype != torch.float32:
+                raise RuntimeError(f"predictions must be float32, got {logits.dtype} / {boxes.dtype}")
+            if logits.device != device or boxes.device != device:
+                raise ValueError("all output sets must be on the same device")
+            logits, boxes = logits.contiguous(), boxes.contiguous()
+            if boxes.data_ptr() % 16:
+                boxes = boxes.clone()
+            keep.append((logits, boxes))
+            dims.append(int(logits.shape[1]))
+        return device, C, keep, dims
+
+    @torch.no_grad()
+    def match_many(self, outputs_list: Sequence[Dict[str, torch.Tensor]],
+                   targets: Union[PackedTargets, Sequence[Dict[str, torch.Tensor]]],
+                   device_indices: bool = False, return_cost: bool = False):
+        """Match S output sets against the same targets.
+
+        Returns a list (per set) of lists (per image) of ``(src, tgt)`` int64 tensors --
+        on the CPU by default, like the reference; views of one device buffer with
+        ``device_indices=True`` (no host synchronisation; input errors are then only
+        raised by ``check_status()``).  With ``return_cost=True`` also returns, per set,
+        the ``[M, Q]`` device cost tensor (rows = packed targets).
+        """
+        S = len(outputs_list)
+        if S == 0:
+            return []
+        batch = targets.batch if isinstance(targets, PackedTargets) else len(targets)
+        device, C, keep, queries = self._prepare_sets(outputs_list, batch)
+        packed = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, device)
+        M, sizes = packed.total, packed.sizes
+
+        if batch == 0 or any(q == 0 for q in queries):
+            if any(q == 0 for q in queries) and batch > 0:
+                raise ValueError("an output set has no queries")
+            return [[] for _ in range(S)]
+
+        sets = (DmSet * S)()
+        cost_off = 0
+        strides = []
+        for s, ((logits, boxes), q) in enumerate(zip(keep, queries)):
+            stride = (q + 3) & ~3
+            sets[s].logits, sets[s].boxes = logits.data_ptr(), boxes.data_ptr()
+            sets[s].cost_off, sets[s].out_off = cost_off, s * M
+            sets[s].Q, sets[s].q_stride = q, stride
+            strides.append((cost_off, stride))
+            cost_off += M * stride
+
+        cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
+        # [src (S*M) | tgt (S*M) | status word]
+        out = torch.empty(2 * S * M + 1, dtype=torch.int64, device=device)
+        out[-1:].zero_()
+        status_ptr = out.data_ptr() + 8 * 2 * S * M
+        params = self._params()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.dm_match_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                                  packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(params),
+                                  cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M, status_ptr, stream)
+        _lib.check(rc, "dm_match_f32")
+
+        pair_counts = [[min(q, t) for t in sizes] for q in queries]
+        if device_indices:
+            self.last_status = out[-1:]
+            flat = out
+        else:
+            host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            torch.cuda.current_stream(device).synchronize()
+            _raise_for_status(int(host[-1].item()) & 0xFFFFFFFF)
+            flat = host
+
+        result = self._split(flat, S, M, sizes, queries, pair_counts, packed.offsets_host)
+        if return_cost:
+            costs = [cost[o:o + M * st].view(M, st)[:, :q] for (o, st), q in zip(strides, queries)]
+            return result, costs
+        return result
+
+    @staticmethod
+    def _split(flat, S, M, sizes, queries, pair_counts, offsets):
+        src_all, tgt_all = flat[:S * M], flat[S * M:2 * S * M]
+        if M == 0:
+            empty = flat[:0]
+            return [[(empty, empty) for _ in sizes] for _ in range(S)]
+        result = []
+        if min(queries) >= max(sizes):
+            # every image's region is completely filled: one split call for everything
+            src_parts = src_all.split(sizes * S)
+            tgt_parts = tgt_all.split(sizes * S)
+            B = len(sizes)
+            for s in range(S):
+                result.append(list(zip(src_parts[s * B:(s + 1) * B], tgt_parts[s * B:(s + 1) * B])))
+            return result
+        for s in range(S):
+            per_image = []
+            for b, n in enumerate(pair_counts[s]):
+                lo = s * M + int(offsets[b])
+                per_image.append((src_all[lo:lo + n], tgt_all[lo:lo + n]))
+            result.append(per_image)
+        return result
+
+    def check_status(self):
+        """Raises the exception the reference would have raised for the last
+        ``device_indices=True`` call (synchronises)."""
+        if self.last_status is not None:
+            _raise_for_status(int(self.last_status.item()) & 0xFFFFFFFF)
+
+    @torch.no_grad()
+    def cost_blocks(self, outputs: Dict[str, torch.Tensor], targets) -> List[torch.Tensor]:
+        """Per-image ``[Q, T_b]`` cost blocks of one output set (device tensors), laid out
+        like the blocks the reference hands to scipy (matcher.py:91-94)."""
+        packed = targets if isinstance(targets, PackedTargets) else \
+            PackedTargets(targets, outputs["pred_logits"].device)
+        _, costs = self.match_many([outputs], packed, device_indices=True, return_cost=True)
+        torch.cuda.current_stream().synchronize()
+        bits = int(self.last_status.item()) & 0xFFFFFFFF
+        _raise_for_status(bits & (_lib.ST_LABEL_RANGE | _lib.ST_DEGENERATE_BOX))
+        off = packed.offsets_host
+        return [costs[0][int(off[b]):int(off[b + 1])].t() for b in range(packed.batch)]

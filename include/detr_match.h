@@ -1,0 +1,125 @@
+/*
+ * detr_match.h -- C ABI of libdetr_match.so, the MI355X (gfx950) implementation of the
+ * DETR-family bipartite-matching path.
+ *
+ * The path it replaces is HungarianMatcher.forward of the reference
+ * (/root/reference/models/matcher.py:38-95) with its box helpers
+ * (/root/reference/utils/box_ops.py:17-21, 32-45, 48-69).  The reference has no FFI of
+ * its own (it is pure Python calling torch and scipy); these entry points are what a
+ * ctypes binding inside that matcher would call.
+ *
+ * Conventions
+ *   - Every pointer marked "device" is GPU memory of the current HIP device; "host"
+ *     pointers are ordinary process memory and are only read during the call.
+ *   - All launches go to `stream` (a hipStream_t passed as void*; NULL = the null stream)
+ *     and the calls return without synchronising.
+ *   - Return value: DM_OK or a negative DM_E_* code for argument / launch errors.
+ *     Data-dependent errors (the exceptions the reference raises) are reported
+ *     asynchronously through the device `status` word as an OR of DM_ST_* bits;
+ *     the caller zeroes it (or calls dm_status_reset) and reads it back after
+ *     synchronising.
+ *
+ * Data layout
+ *   One call handles S "output sets" (decoder layers, two-stage encoder head ...) over the
+ *   same B images and the same targets.  Problem (s, b) matches the Q_s queries of set s
+ *   in image b to the T_b targets of image b.
+ *   - targets are packed over the batch: tgt_labels[M], tgt_boxes[M][4] (cxcywh),
+ *     tgt_off[B+1] exclusive prefix sums of T_b, M = tgt_off[B].
+ *   - cost of set s: rows are TARGETS: cost[set.cost_off + (tgt_off[b] + t) * set.q_stride + q]
+ *     is the matching cost of query q and target t of image b, i.e. the transpose of the
+ *     reference's per-image block C[b][:, off_b:off_b+T_b] (matcher.py:91-94).
+ *     A set's region is M * q_stride floats.
+ *   - indices of set s: image b's min(Q_s, T_b) pairs are written to
+ *     src_out/tgt_out[set.out_off + tgt_off[b] + k], src ascending -- the order
+ *     scipy.optimize.linear_sum_assignment returns (matcher.py:94-95).  A set's region is
+ *     M int64 entries; entries beyond min(Q_s, T_b) of an image are left untouched.
+ */
+#ifndef DETR_MATCH_H
+#define DETR_MATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_ABI_VERSION 1
+#define DM_MAX_SETS_PER_LAUNCH 16
+
+/* return codes */
+#define DM_OK 0
+#define DM_E_INVALID_ARG (-1)
+#define DM_E_LAUNCH (-2)       /* a HIP call failed; dm_last_hip_error() has the text */
+#define DM_E_UNSUPPORTED (-3)  /* problem exceeds a documented limit */
+
+/* status-word bits (device int32), and the exception the reference raises for each */
+#define DM_ST_LABEL_RANGE 1     /* IndexError: label outside [-C, C)   (matcher.py:73,81) */
+#define DM_ST_DEGENERATE_BOX 2  /* AssertionError: x1<x0, y1<y0 or NaN (box_ops.py:59-60) */
+#define DM_ST_INVALID_COST 4    /* ValueError: NaN or -inf cost entry  (scipy, matcher.py:94) */
+#define DM_ST_INFEASIBLE 8      /* ValueError: cost matrix is infeasible (scipy) */
+
+/* One output set: the `output` dict of one matcher call (matcher.py:43-45). */
+typedef struct DmSet {
+    const float *logits;  /* device, [B, Q, C] contiguous      (outputs["pred_logits"]) */
+    const float *boxes;   /* device, [B, Q, 4] contiguous cxcywh (outputs["pred_boxes"]) */
+    int64_t cost_off;     /* element offset of this set's region in the cost buffer */
+    int64_t out_off;      /* element offset of this set's region in src_out / tgt_out */
+    int32_t Q;            /* queries per image */
+    int32_t q_stride;     /* row stride of the cost region in floats, >= Q */
+} DmSet;
+
+/* Matcher hyper-parameters: HungarianMatcher.__init__ (matcher.py:21-36). */
+typedef struct DmParams {
+    int32_t cls_mode;     /* 0: 'ce' softmax class cost (matcher.py:68-73); 1: focal (74-81) */
+    float w_class;        /* cost_class */
+    float w_bbox;         /* cost_bbox  */
+    float w_giou;         /* cost_giou  */
+    float focal_alpha;
+    float focal_gamma;
+} DmParams;
+
+int dm_abi_version(void);
+const char *dm_strerror(int code);
+const char *dm_last_hip_error(void);
+
+/* Number of GPUs HIP sees; <= 0 when there is none (the library still loads). */
+int dm_device_count(void);
+
+/*
+ * Fused matching-cost kernel: replaces matcher.py:59-90 and box_ops.py:17-69 for the
+ * B diagonal blocks the reference consumes (class cost + L1 + GIoU, weighted sum).
+ *   sets     host, S entries            tgt_labels device int64[M]
+ *   tgt_boxes device float[M][4]        tgt_off    device int32[B+1]
+ *   max_T    host-known max_b T_b       cost       device, see layout above
+ *   status   device int32[1], OR-ed with DM_ST_LABEL_RANGE / DM_ST_DEGENERATE_BOX
+ * Prediction boxes of every image are validated, also of images without targets,
+ * as the reference's batch-wide assert does.
+ */
+int dm_cost_f32(const DmSet *sets, int S, int B, int C,
+                const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
+                int max_T, const DmParams *params, float *cost, int32_t *status, void *stream);
+
+/*
+ * Batched rectangular linear-sum-assignment: replaces the per-image
+ * scipy.optimize.linear_sum_assignment loop (matcher.py:93-95) for all S*B problems in
+ * one pass, reproducing scipy's result including its choice among tied optima.
+ *   cost     device, layout above (produced by dm_cost_f32 or by the caller)
+ *   order    device int32[B] or NULL: image processing order (largest T first helps)
+ *   src_out, tgt_out  device int64, layout above
+ *   status   OR-ed with DM_ST_INVALID_COST / DM_ST_INFEASIBLE
+ * Limits: min(Q, T) <= 4096 and max(Q, T) <= 4096 per problem (DM_E_UNSUPPORTED beyond).
+ */
+int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost,
+               const int32_t *tgt_off, const int32_t *order, int max_T,
+               int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
+
+/* dm_cost_f32 followed by dm_lap_f32 on the same stream: one whole matcher step. */
+int dm_match_f32(const DmSet *sets, int S, int B, int C,
+                 const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
+                 const int32_t *order, int max_T, const DmParams *params,
+                 float *cost, int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETR_MATCH_H */

@@ -66,3 +66,45 @@ def load(name):
 def assignment_cost(cost_qt, src, tgt):
     """Total matched cost in fp64 on a [Q, T] block."""
     return float(np.asarray(cost_qt, dtype=np.float64)[src, tgt].sum())
+
+
+# --------------------------------------------------------------------------------------
+# cost tolerance
+# --------------------------------------------------------------------------------------
+COST_RTOL, COST_ATOL = 1e-5, 1e-6
+
+
+def _focal64_from_p(p, alpha, gamma):
+    neg = (1 - alpha) * p ** gamma * (-np.log(1 - p + 1e-8))
+    pos = alpha * (1 - p) ** gamma * (-np.log(p + 1e-8))
+    return pos - neg
+
+
+def focal_sensitivity(logits_qc, labels, alpha, gamma, ulps=2.0):
+    """[Q, T] change of the focal class term (matcher.py:76-81) when sigmoid(x) moves by
+    +-`ulps` fp32 ulps.  The term contains log(1 - p): for p -> 1 one ulp of p is a large
+    relative change of 1 - p, so two correct fp32 evaluations of the reference's formula
+    (different exp implementations) legitimately differ by this much."""
+    x = np.asarray(logits_qc, dtype=np.float64)[:, np.asarray(labels, dtype=np.int64)]
+    p = 1.0 / (1.0 + np.exp(-x))
+    eps = ulps * 2.0 ** -24
+    hi = np.minimum(p * (1 + eps), 1.0)
+    lo = p * (1 - eps)
+    return np.abs(_focal64_from_p(hi, alpha, gamma) - _focal64_from_p(lo, alpha, gamma))
+
+
+def assert_cost_close(got_qt, ref_qt, logits_qc, labels, cls_loss, w_class, alpha, gamma):
+    """The north-star bar -- 1e-5 relative in fp32 -- widened, for the focal class term only,
+    by that term's own sensitivity to a 2-ulp change of sigmoid(x)."""
+    got = np.asarray(got_qt, dtype=np.float64)
+    ref = np.asarray(ref_qt, dtype=np.float64)
+    assert got.shape == ref.shape
+    tol = COST_RTOL * np.abs(ref) + COST_ATOL
+    if cls_loss != "ce" and ref.size:
+        tol = tol + abs(w_class) * focal_sensitivity(logits_qc, labels, alpha, gamma)
+    err = np.abs(got - ref)
+    bad = ~(err <= tol)
+    assert not bad.any(), "cost mismatch: %d of %d entries, worst |err| %.3e (tol %.3e)" % (
+        bad.sum(), bad.size, err[bad].max(), tol[bad][np.argmax(err[bad])])
+    strict = err <= COST_RTOL * np.abs(ref) + COST_ATOL
+    return float(strict.mean()) if ref.size else 1.0

@@ -1,0 +1,263 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors, the CPU
+oracle and scipy.
+
+Bars (BASELINE.json north_star): cost entries within 1e-5 relative in fp32 (for the focal
+class term widened by its sensitivity to a 2-ulp change of sigmoid(x), see
+golden_io.assert_cost_close); assignments
+bit-exact wherever the optimum is unique; total matched cost within 1e-5 relative where
+ties exist.  The assignment kernel on its own is held to a stricter bar: bit-exact against
+scipy on the SAME cost matrix, ties included.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+OK_CASES = [n for n in golden_io.case_names() if golden_io.load(n).error is None]
+ERR_CASES = [n for n in golden_io.case_names() if golden_io.load(n).error is not None]
+
+
+def _matcher(**kw):
+    import detr_amd
+
+    return detr_amd.HungarianMatcher(**kw)
+
+
+def _assert_same_or_equal_cost(cost_qt, got, ref):
+    gs, gt = got[0].numpy(), got[1].numpy()
+    rs, rt = np.asarray(ref[0]), np.asarray(ref[1])
+    assert gs.dtype == np.int64 and gt.dtype == np.int64
+    assert len(gs) == len(rs) == len(gt)
+    if np.array_equal(gs, rs) and np.array_equal(gt, rt):
+        return True
+    # not the same pairs: must be another optimum of equal value on the reference's cost
+    assert len(set(gs.tolist())) == len(gs) and len(set(gt.tolist())) == len(gt)
+    a = golden_io.assignment_cost(cost_qt, gs, gt)
+    r = golden_io.assignment_cost(cost_qt, rs, rt)
+    assert abs(a - r) <= 1e-5 * max(1.0, abs(r)), (a, r)
+    return False
+
+
+@pytest.mark.parametrize("name", OK_CASES)
+def test_golden_costs(name):
+    g = golden_io.load(name)
+    outputs, targets = g.torch_inputs("cuda")
+    blocks = _matcher(**g.matcher_kwargs()).cost_blocks(outputs, targets)
+    for b in range(g.B):
+        got = blocks[b].cpu().numpy()
+        assert got.shape == (g.Q, g.sizes[b])
+        strict = golden_io.assert_cost_close(got, g.cost[b], g.logits[b], g.labels[b], g.cls_loss,
+                                             g.weights[0], g.alpha, g.gamma)
+        assert strict >= 0.995      # share of entries inside the plain 1e-5 relative bar
+
+
+@pytest.mark.parametrize("name", OK_CASES)
+def test_golden_indices(name):
+    g = golden_io.load(name)
+    outputs, targets = g.torch_inputs("cuda")
+    got = _matcher(**g.matcher_kwargs())(outputs, targets)
+    assert len(got) == g.B
+    for b in range(g.B):
+        assert got[b][0].device.type == "cpu" and got[b][0].dtype == torch.int64
+        _assert_same_or_equal_cost(g.cost[b], got[b], g.indices[b])
+
+
+@pytest.mark.parametrize("name", ERR_CASES)
+def test_golden_errors(name):
+    g = golden_io.load(name)
+    outputs, targets = g.torch_inputs("cuda")
+    with pytest.raises(g.error):
+        _matcher(**g.matcher_kwargs())(outputs, targets)
+
+
+def test_cpu_tensors_are_rejected():
+    g = golden_io.load("ce_c3_q50")
+    outputs, targets = g.torch_inputs("cpu")
+    with pytest.raises(RuntimeError):
+        _matcher(**g.matcher_kwargs())(outputs, targets)
+
+
+def _lsap_matrices(rng):
+    mats = []
+    for _ in range(40):     # T < Q: the register kernel
+        q, t = int(rng.integers(2, 700)), int(rng.integers(1, 60))
+        mats.append(rng.standard_normal((q, t)).astype(np.float32))
+    for _ in range(40):     # heavy ties
+        q, t = int(rng.integers(2, 300)), int(rng.integers(1, 40))
+        mats.append(rng.integers(0, 3, (q, t)).astype(np.float32))
+    for _ in range(20):     # one-decimal costs
+        q, t = int(rng.integers(2, 200)), int(rng.integers(1, 50))
+        mats.append(np.round(rng.random((q, t)), 1).astype(np.float32))
+    for _ in range(20):     # T >= Q: scipy does not transpose
+        q = int(rng.integers(1, 40))
+        t = q + int(rng.integers(0, 40))
+        mats.append(rng.integers(0, 4, (q, t)).astype(np.float32))
+    for shape in [(1, 1), (9, 1), (1, 9), (7, 7), (64, 5), (65, 64), (128, 127), (129, 3), (1088, 17), (1089, 5),
+                  (1500, 30), (320, 100), (321, 100), (640, 2), (641, 2)]:
+        mats.append(np.zeros(shape, dtype=np.float32))
+        mats.append(rng.standard_normal(shape).astype(np.float32))
+    m = rng.random((60, 9)).astype(np.float32)
+    m[:, 2] = np.inf
+    m[4, 2] = 0.25
+    mats.append(m)
+    return mats
+
+
+@pytest.mark.parametrize("force_generic", [0, 1])
+def test_lsap_bit_exact_vs_scipy(force_generic):
+    import detr_amd
+
+    rng = np.random.default_rng(99)
+    mats = _lsap_matrices(rng)
+    detr_amd.lib.dm_debug_force_generic_lap(force_generic)
+    try:
+        got = detr_amd.batched_linear_sum_assignment([torch.from_numpy(m).cuda() for m in mats])
+    finally:
+        detr_amd.lib.dm_debug_force_generic_lap(0)
+    for m, (r, c) in zip(mats, got):
+        rs, cs = linear_sum_assignment(m)
+        np.testing.assert_array_equal(r.numpy(), rs, err_msg=str(m.shape))
+        np.testing.assert_array_equal(c.numpy(), cs, err_msg=str(m.shape))
+
+
+def test_lsap_errors():
+    import detr_amd
+
+    for force in (0, 1):
+        detr_amd.lib.dm_debug_force_generic_lap(force)
+        try:
+            for bad in (np.nan, -np.inf):
+                m = np.ones((30, 4), dtype=np.float32)
+                m[17, 2] = bad
+                with pytest.raises(ValueError):
+                    detr_amd.batched_linear_sum_assignment([torch.from_numpy(m).cuda()])
+            m = np.full((30, 4), np.inf, dtype=np.float32)
+            with pytest.raises(ValueError):
+                detr_amd.batched_linear_sum_assignment([torch.from_numpy(m).cuda()])
+        finally:
+            detr_amd.lib.dm_debug_force_generic_lap(0)
+
+
+def _check_workload(name, batch=None, lap_sample=None):
+    """match_many on a full workload: GPU assignment bit-exact vs scipy on the GPU's own cost,
+    cost vs the CPU oracle within tolerance, end-to-end vs the CPU oracle."""
+    import detr_amd
+    from detr_amd import synth
+    from oracle import oracle
+
+    wl, sets, targets = synth.make_workload(name, device="cpu", batch=batch)
+    dev_sets = [{k: v.cuda() for k, v in s.items()} for s in sets]
+    dev_targets = [{k: v.cuda() for k, v in t.items()} for t in targets]
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    result, costs = matcher.match_many(dev_sets, dev_targets, return_cost=True)
+    sizes = [len(t["labels"]) for t in targets]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    rng = np.random.default_rng(0)
+    exact = total = 0
+    for s, out in enumerate(sets):
+        B, Q = out["pred_logits"].shape[:2]
+        cost_s = costs[s].cpu().numpy()          # [M, Q]
+        images = range(B) if lap_sample is None else rng.choice(B, size=min(lap_sample, B), replace=False)
+        ref = None
+        if lap_sample is None:
+            ref, ref_cost = oracle.match(out["pred_logits"].numpy(), out["pred_boxes"].numpy(),
+                                         [t["labels"].numpy() for t in targets],
+                                         [t["boxes"].numpy() for t in targets],
+                                         return_cost=True, **wl.matcher_kwargs)
+        for b in images:
+            gs, gt = result[s][b][0].numpy(), result[s][b][1].numpy()
+            n = min(Q, sizes[b])
+            assert len(gs) == n and len(gt) == n
+            if n == 0:
+                continue
+            blk = cost_s[off[b]:off[b + 1]].T    # [Q, T_b], the argument scipy would get
+            rs, cs = linear_sum_assignment(blk)
+            np.testing.assert_array_equal(gs, rs)
+            np.testing.assert_array_equal(gt, cs)
+            if ref is not None:
+                kw = wl.matcher_kwargs
+                golden_io.assert_cost_close(blk, ref_cost[b], out["pred_logits"][b].numpy(),
+                                            targets[b]["labels"].numpy(), kw["cls_loss"], kw["cost_class"],
+                                            kw["focal_alpha"], kw["focal_gamma"])
+                exact += _assert_same_or_equal_cost(ref_cost[b], result[s][b], ref[b])
+                total += 1
+    return exact, total
+
+
+def test_workload_cfg1_full():
+    exact, total = _check_workload("cfg1")
+    assert exact >= 0.99 * total
+
+
+def test_workload_cfg2_full():
+    exact, total = _check_workload("cfg2")
+    assert exact >= 0.99 * total
+
+
+def test_workload_cfg3_first_stage_hw():
+    exact, total = _check_workload("cfg3_hw", batch=16)
+    assert exact >= 0.99 * total
+
+
+def test_workload_cfg4_reduced_batch():
+    exact, total = _check_workload("cfg4", batch=24)
+    assert exact >= 0.99 * total
+
+
+def test_workload_cfg4_full_size_properties():
+    """Full cfg4 (B=256, Q=900, C=91, heavy-tail T): permutation validity everywhere,
+    scipy equality on a sample of problems."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg4", device="cuda")
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    result = matcher.match_many(sets, targets)
+    sizes = [len(t["labels"]) for t in targets]
+    for s in range(len(sets)):
+        Q = sets[s]["pred_logits"].shape[1]
+        for b, (src, tgt) in enumerate(result[s]):
+            n = min(Q, sizes[b])
+            src, tgt = src.numpy(), tgt.numpy()
+            assert len(src) == n
+            assert np.all(np.diff(src) > 0) and (n == 0 or (src[0] >= 0 and src[-1] < Q))
+            assert sorted(tgt.tolist()) == list(range(n)) if n == sizes[b] else len(set(tgt.tolist())) == n
+    # idempotence: a second call gives the same answer
+    again = matcher.match_many(sets, targets)
+    for s in range(len(sets)):
+        for (a0, a1), (b0, b1) in zip(result[s], again[s]):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    _check_workload("cfg4", lap_sample=24)
+
+
+def test_image_order_invariance():
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg2", device="cuda", batch=16)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    base = matcher(sets[0], targets)
+    perm = torch.randperm(16, generator=torch.Generator().manual_seed(3)).tolist()
+    shuffled = {k: v[perm].contiguous() for k, v in sets[0].items()}
+    got = matcher(shuffled, [targets[i] for i in perm])
+    for k, i in enumerate(perm):
+        assert torch.equal(got[k][0], base[i][0]) and torch.equal(got[k][1], base[i][1])
+
+
+def test_device_indices_mode_matches_cpu_mode():
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg3", device="cuda", batch=8)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    cpu = matcher.match_many(sets, targets)
+    dev = matcher.match_many(sets, targets, device_indices=True)
+    matcher.check_status()
+    for s in range(len(sets)):
+        for (a0, a1), (b0, b1) in zip(cpu[s], dev[s]):
+            assert b0.device.type == "cuda"
+            assert torch.equal(a0, b0.cpu()) and torch.equal(a1, b1.cpu())

@@ -23,7 +23,8 @@ def test_cost_block_matches_reference(name):
             continue
         got = oracle.cost_block(g.logits[b], g.pboxes[b], g.labels[b], g.tboxes[b], **g.matcher_kwargs())
         # north-star tolerance: 1e-5 relative in fp32 (transcendentals differ by an ulp between libms)
-        np.testing.assert_allclose(got, g.cost[b], rtol=1e-5, atol=1e-6)
+        golden_io.assert_cost_close(got, g.cost[b], g.logits[b], g.labels[b], g.cls_loss, g.weights[0],
+                                    g.alpha, g.gamma)
 
 
 @pytest.mark.parametrize("name", OK_CASES)
