@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the matching hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2]
+
+A "step" is one pass of the matcher over one batch: all Hungarian-matched output sets of
+one training step (cfg2: B=64 images, 6 decoder-layer sets, Q=600, ~16 targets per image,
+focal class cost) from "predictions and targets resident in HBM" to "CPU int64 index
+tensors in the caller's hands" -- i.e. packing the targets, the cost kernel, the
+assignment kernel, the device-to-host copy of the indices and the stream synchronisation.
+With N > 1 (one process per GPU, launched by torch.distributed.run) every rank matches
+its own B images (weak scaling) and the step also carries the single collective of the
+path, the all-reduce of the matched-box counts.
+
+Prints one JSON line: whole-job matched images/s, plus
+  roofline      cost kernel: algorithmic bytes per step / HIP-event time per step, vs 8 TB/s
+  cpu_baseline  the reference's CPU formulation (torch ops on the whole batch + scipy per
+                image, restated in oracle/torch_pipeline.py) timed on this host, rank 0, N=1.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+
+def cost_kernel_bytes(set_queries, n_logits, sizes):
+    """Algorithmic bytes of one step's cost launches: logits + prediction boxes read,
+    target boxes + int64 labels read once per problem, cost entries written."""
+    total = 0
+    for q in set_queries:
+        for t in sizes:
+            total += q * n_logits * 4 + q * 16 + t * (16 + 8) + q * t * 4
+    return total
+
+
+def cpu_baseline(wl, sets, targets, budget_s=20.0):
+    from oracle import torch_pipeline
+
+    cpu_sets = [{k: v.cpu() for k, v in s.items()} for s in sets]
+    cpu_targets = [{k: v.cpu() for k, v in t.items()} for t in targets]
+    B = len(cpu_targets)
+    # one untimed call to warm the allocator / thread pool
+    torch_pipeline.match(cpu_sets[0]["pred_logits"][:2], cpu_sets[0]["pred_boxes"][:2], cpu_targets[:2],
+                         **wl.matcher_kwargs)
+    done, t0 = 0, time.perf_counter()
+    for s in cpu_sets:
+        torch_pipeline.match(s["pred_logits"], s["pred_boxes"], cpu_targets, **wl.matcher_kwargs)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    elapsed = time.perf_counter() - t0
+    step_s = elapsed * len(cpu_sets) / done
+    return {
+        "value": B / step_s, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{done} of {len(cpu_sets)} matcher calls of one {wl.name} step (B={B}) in {elapsed:.1f} s, "
+                  f"scaled to the full step; torch {torch.__version__} CPU ops on the whole-batch "
+                  f"[B*Q, sum T] matrix + scipy per image",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import detr_amd
+    from detr_amd import synth
+    from detr_amd.dist import all_reduce_num_boxes, matched_box_counts
+
+    wl, sets, targets = synth.make_workload(args.workload, device=device, batch=args.batch, rank=rank)
+    B = len(targets)
+    sizes = [len(t["labels"]) for t in targets]
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    counts = matched_box_counts(sizes, wl.set_queries)
+
+    def step():
+        if world > 1:
+            num_boxes = all_reduce_num_boxes(counts, device)   # overlaps the kernels below
+        indices = matcher.match_many(sets, targets)
+        return indices
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+
+    detr_amd.lib.dm_profile_enable(1)
+    cost_ms = ctypes.c_float()
+    lap_ms = ctypes.c_float()
+    cost_ms_sum = lap_ms_sum = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # match_many has synchronised the stream: the step's events are complete
+        detr_amd.lib.dm_profile_read(ctypes.byref(cost_ms), ctypes.byref(lap_ms))
+        cost_ms_sum += cost_ms.value
+        lap_ms_sum += lap_ms.value
+    fence()
+    elapsed = time.perf_counter() - t0
+    detr_amd.lib.dm_profile_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        cost_ms_avg = cost_ms_sum / args.steps
+        lap_ms_avg = lap_ms_sum / args.steps
+        algo_bytes = cost_kernel_bytes(wl.set_queries, wl.n_logits, sizes)
+        achieved = algo_bytes / (cost_ms_avg * 1e-3) / 1e9
+        record = {
+            "metric": "matched images/sec (Q=600, ~16 GT/img, 6 aux layers); cost-kernel HBM GB/s",
+            "value": world * B * args.steps / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{wl.name}: B={B} images per GPU, sets Q={wl.set_queries}, C={wl.n_logits}, "
+                                   f"{wl.cls_loss} class cost, T~{wl.t_law} (sum T={sum(sizes)}, max T={max(sizes)}), "
+                                   f"{len(wl.set_queries) * B} assignment problems per step per GPU",
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "cost_kernel", "algorithmic_bytes_per_step": algo_bytes,
+                         "ms_per_step_hip_events": cost_ms_avg},
+            "lap": {"kernel": "lap_wave_kernel", "ms_per_step_hip_events": lap_ms_avg,
+                    "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            record["cpu_baseline"] = cpu_baseline(wl, sets, targets)
+        print(json.dumps(record), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

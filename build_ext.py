@@ -1,6 +1,6 @@
 """Builds libdetr_match.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
 
-    python -m detr_amd.build [--force]
+    python build_ext.py [--force]
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the
 resulting shared object travels with the tree to the GPU box.
@@ -10,8 +10,8 @@ import shutil
 import subprocess
 import sys
 
-PKG = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(PKG)
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "detr_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdetr_match.so")
 SOURCES = ["cost_kernel.hip", "lap_kernel.hip", "abi.hip"]

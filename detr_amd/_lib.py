@@ -6,6 +6,11 @@ raises, and so does every matcher call.
 import ctypes
 import os
 
+# torch first: its bundled libamdhip64.so.7 must be the HIP runtime of the process.  Loading
+# libdetr_match.so before torch would bind the same SONAME to /opt/rocm's copy, and torch's
+# own HSA runtime then fails to find the device.
+import torch  # noqa: F401
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libdetr_match.so")
 
@@ -29,13 +34,14 @@ class DmParams(ctypes.Structure):
 
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
-           "dm_cost_f32", "dm_lap_f32", "dm_match_f32"]
+           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_profile_enable", "dm_profile_read",
+           "dm_debug_force_generic_lap"]
 
 
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: build the HIP extension with `python -m detr_amd.build` "
+            f"{LIB_PATH} is missing: build the HIP extension with `python build_ext.py` "
             "(there is no CPU fallback for the matching path)")
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64p = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
@@ -56,6 +62,10 @@ def _load():
     lib.dm_match_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, prmp, vp, i64p, i64p, vp, vp]
     lib.dm_debug_force_generic_lap.restype = None
     lib.dm_debug_force_generic_lap.argtypes = [ctypes.c_int]
+    lib.dm_profile_enable.restype = ctypes.c_int
+    lib.dm_profile_enable.argtypes = [ctypes.c_int]
+    lib.dm_profile_read.restype = ctypes.c_int
+    lib.dm_profile_read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
     if lib.dm_abi_version() != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.dm_abi_version()} != {ABI_VERSION}; rebuild it")
     return lib

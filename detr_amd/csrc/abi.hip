@@ -21,12 +21,43 @@ extern "C" int dm_device_count(void)
     return n;
 }
 
+namespace {
+// optional timing of the two kernel groups of dm_match_f32 with HIP events on the call's stream
+bool g_profile = false;
+hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+bool g_ev_valid = false;
+}  // namespace
+
+extern "C" int dm_profile_enable(int on)
+{
+    g_profile = on != 0;
+    g_ev_valid = false;
+    if (g_profile && !g_ev[0]) {
+        for (auto &e : g_ev)
+            if (hipEventCreate(&e) != hipSuccess) { g_profile = false; return DM_E_LAUNCH; }
+    }
+    return DM_OK;
+}
+
+extern "C" int dm_profile_read(float *cost_ms, float *lap_ms)
+{
+    if (!g_profile || !g_ev_valid || !cost_ms || !lap_ms) return DM_E_INVALID_ARG;
+    if (hipEventElapsedTime(cost_ms, g_ev[0], g_ev[1]) != hipSuccess) return DM_E_LAUNCH;
+    if (hipEventElapsedTime(lap_ms, g_ev[1], g_ev[2]) != hipSuccess) return DM_E_LAUNCH;
+    return DM_OK;
+}
+
 extern "C" int dm_match_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
                             const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
                             const DmParams *params, float *cost, int64_t *src_out, int64_t *tgt_out,
                             int32_t *status, void *stream)
 {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g_profile) (void)hipEventRecord(g_ev[0], st);
     int rc = dm_cost_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, max_T, params, cost, status, stream);
     if (rc != DM_OK) return rc;
-    return dm_lap_f32(sets, S, B, cost, tgt_off, order, max_T, src_out, tgt_out, status, stream);
+    if (g_profile) (void)hipEventRecord(g_ev[1], st);
+    rc = dm_lap_f32(sets, S, B, cost, tgt_off, order, max_T, src_out, tgt_out, status, stream);
+    if (g_profile) { (void)hipEventRecord(g_ev[2], st); g_ev_valid = rc == DM_OK; }
+    return rc;
 }

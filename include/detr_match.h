@@ -16,8 +16,7 @@
  *   - Return value: DM_OK or a negative DM_E_* code for argument / launch errors.
  *     Data-dependent errors (the exceptions the reference raises) are reported
  *     asynchronously through the device `status` word as an OR of DM_ST_* bits;
- *     the caller zeroes it (or calls dm_status_reset) and reads it back after
- *     synchronising.
+ *     the caller zeroes it before the call and reads it back after synchronising.
  *
  * Data layout
  *   One call handles S "output sets" (decoder layers, two-stage encoder head ...) over the
@@ -118,6 +117,19 @@ int dm_match_f32(const DmSet *sets, int S, int B, int C,
                  const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
                  const int32_t *order, int max_T, const DmParams *params,
                  float *cost, int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
+
+/*
+ * Measurement aids (no counterpart in the reference).  With profiling enabled,
+ * dm_match_f32 records HIP events on its stream before the cost kernels, between the cost
+ * and the assignment kernels, and after the assignment kernels; dm_profile_read returns the
+ * two elapsed times of the most recent dm_match_f32 call in milliseconds and must be called
+ * after that call's stream has been synchronised.  Not thread-safe.
+ */
+int dm_profile_enable(int on);
+int dm_profile_read(float *cost_ms, float *lap_ms);
+
+/* Testing aid: non-zero routes every assignment problem through the list-order kernel. */
+void dm_debug_force_generic_lap(int on);
 
 #ifdef __cplusplus
 }
