@@ -11,11 +11,12 @@
 //     among the remaining columns of minimal reduced cost, take the unassigned one at
 //     the LARGEST list position if there is one, else the one at the SMALLEST position.
 //
-// One wavefront solves one (set, image) problem; there is no inter-workgroup traffic.
-//   lap_wave_kernel<NCOL>  T < Q <= 64*NCOL: every lane owns NCOL columns (queries) and
-//                          keeps their reduced cost, dual, assignment and predecessor in
-//                          registers; the column minimum is a DPP wave reduction; the
-//                          first rows of the cost block are staged in LDS.
+// One workgroup solves one (set, image) problem; there is no inter-workgroup traffic.
+//   lap_block_kernel<NCOL> T < Q <= 1088: a workgroup of 1..16 wavefronts per problem; every
+//                          thread owns NCOL columns (queries) and keeps their reduced cost,
+//                          dual, assignment and predecessor in registers; column minima are
+//                          DPP wave reductions combined through LDS; the first rows of the
+//                          cost block are staged in LDS by LDS-DMA.
 //   lap_generic_kernel     any shape up to 4096 x 4096 (also T >= Q, where scipy does
 //                          not transpose): literal list-order scan with all state in LDS.
 #include "dm_common.h"
@@ -53,16 +54,26 @@ __device__ __forceinline__ void emit_pair(bool has, int query, int target, int &
     base += __popcll(bal);
 }
 
+// One workgroup of W wavefronts (W = blockDim.x / 64, 1..16) per problem with T < Q <= 64*W*NCOL.
+// Thread `tid` owns the columns (queries) j = tid + 64*W*k, k < NCOL, and keeps their reduced
+// cost, dual, assignment, predecessor and list position in registers.  Per Dijkstra step:
+// every wave reduces its own columns with DPP (minimum, then the tie key among the minima),
+// lane 0 publishes (min, key, column, assigned row) in LDS, one barrier, and every wave
+// reduces the W published records again -- so all waves agree on the step's column without a
+// second barrier (the records are double-buffered by step parity).
 template <int NCOL>
-__global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, const int S,
-                                                       const float *__restrict__ cost,
-                                                       const int32_t *__restrict__ tgt_off,
-                                                       const int32_t *__restrict__ order,
-                                                       int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
-                                                       int32_t *status, const int t_cap, const int lds_cost_floats)
+__global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL)) void lap_block_kernel(const DmSetArray sets, const int S,
+                                                         const float *__restrict__ cost,
+                                                         const int32_t *__restrict__ tgt_off,
+                                                         const int32_t *__restrict__ order,
+                                                         int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
+                                                         int32_t *status, const int t_cap, const int lds_cost_floats)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int BS = blockDim.x, W = BS >> 6;
+    const int QCAP = BS * NCOL;
     const int s = blockIdx.x % S;
     const int bi = blockIdx.x / S;
     const int b = order ? order[bi] : bi;
@@ -70,152 +81,180 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
     const int nc = set.Q;                 // columns = queries
     const int t0 = tgt_off[b];
     const int nr = tgt_off[b + 1] - t0;   // rows = targets
-    if (nr == 0 || nr >= nc || nc > 64 * NCOL) return;   // not this kernel's problem
+    if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
+#ifdef DM_LAP_STAMPS
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_c1 = 0;
+    int st_iters = 0;
+    unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_n = 0;
+#define DM_STAMP(idx) { st_n = __builtin_amdgcn_s_memtime(); st_seg[idx] += st_n - st_t; st_t = st_n; }
+#else
+#define DM_STAMP(idx)
+#endif
 
-    constexpr int QCAP = 64 * NCOL;
-    double *u = reinterpret_cast<double *>(smem);          // [t_cap] row duals
-    int2 *undo = reinterpret_cast<int2 *>(u + t_cap);      // [t_cap] (position, column) moved per removal
-    int *col4row = reinterpret_cast<int *>(undo + t_cap);  // [t_cap]
-    int *row4col = col4row + t_cap;                        // [QCAP]
-    int *pathL = row4col + QCAP;                           // [QCAP]
-    int *remaining = pathL + QCAP;                         // [QCAP] list position -> column
-    int *pos = remaining + QCAP;                           // [QCAP] column -> list position
-    float *crow = reinterpret_cast<float *>(pos + QCAP);   // [lds_cost_floats] first rows of the block
+    double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
+    double *sval = u + t_cap;                               // [2][16] published wave minima
+    unsigned *skey = reinterpret_cast<unsigned *>(sval + 32);   // [2][16] tie keys
+    int *sj = reinterpret_cast<int *>(skey + 32);           // [2][16] column of the wave's candidate
+    int *sr = sj + 32;                                      // [2][16] row assigned to that column, or -1
+    int *col4row = sr + 32;                                 // [t_cap]
+    int *row4col = col4row + t_cap;                         // [QCAP]
+    int *pathL = row4col + QCAP;                            // [QCAP]
+    int *remaining = pathL + QCAP;                          // [QCAP] list position -> column
+    float *crow = reinterpret_cast<float *>(remaining + QCAP);   // [lds_cost_floats] first rows of the block
 
     const int qs = set.q_stride;
     const float *cg = cost + set.cost_off + (size_t)t0 * qs;
-    const int R = min(nr, lds_cost_floats / nc);           // rows resident in LDS
+    const int R = min(nr, lds_cost_floats / nc);            // rows resident in LDS
 
     double v[NCOL], spc[NCOL];
-    int r4c[NCOL], pth[NCOL];
+    int r4c[NCOL], pth[NCOL], jc[NCOL], posr[NCOL];
     unsigned valid = 0;
 #pragma unroll
     for (int k = 0; k < NCOL; ++k) {
-        const int j = lane + 64 * k;
+        const int j = tid + BS * k;
         v[k] = 0.0; spc[k] = INF; r4c[k] = -1; pth[k] = -1;
+        jc[k] = min(j, nc - 1);      // columns past the end alias the last one and are never live
+        posr[k] = nc - 1 - j;
         if (j < nc) {
             valid |= 1u << k;
             row4col[j] = -1;
-            remaining[j] = nc - 1 - j;
-            pos[j] = nc - 1 - j;
+            remaining[nc - 1 - j] = j;
         }
     }
-    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    for (int i = tid; i < nr; i += BS) { u[i] = 0.0; col4row[i] = -1; }
 
-    // stage the first R rows; every entry read is validated (the others are on first touch)
+    // Stage the first R rows in LDS.  A dense, 16-byte aligned block goes through LDS-DMA
+    // (no registers, every piece in flight at once); anything else through registers.
+    const int nfl = R * nc;
     bool bad = false;
-    for (int i = 0; i < R; ++i) {
+    if (qs == nc && (nc & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0) {
+        for (int base = wave * 256; base < nfl; base += W * 256) {
+            const int e = base + lane * 4;
+            if (e < nfl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(cg + e),
+                                                 (__attribute__((address_space(3))) void *)(crow + base), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int e = tid * 4; e < nfl; e += BS * 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(crow + e);
+            bad |= cost_is_invalid(x.x) | cost_is_invalid(x.y) | cost_is_invalid(x.z) | cost_is_invalid(x.w);
+        }
+    } else {
+        for (int i = 0; i < R; ++i) {
+            float c[NCOL];
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) {
-            const int j = lane + 64 * k;
-            if ((valid >> k) & 1u) {
-                const float c = cg[(size_t)i * qs + j];
-                bad |= cost_is_invalid(c);
-                crow[i * nc + j] = c;
+            for (int k = 0; k < NCOL; ++k) c[k] = cg[(size_t)i * qs + jc[k]];
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) {
+                bad |= cost_is_invalid(c[k]);
+                crow[i * nc + jc[k]] = c[k];
             }
         }
     }
-    if (__any(bad)) {
-        if (lane == 0) dm::raise_status(status, DM_ST_INVALID_COST);
+    if (__syncthreads_or(bad)) {
+        if (tid == 0) dm::raise_status(status, DM_ST_INVALID_COST);
         return;
     }
-    __syncthreads();
 
-    int nundo = 0;
+#ifdef DM_LAP_STAMPS
+    st_c1 = __builtin_amdgcn_s_memtime();
+#endif
+    int par = 0;
     for (int cur = 0; cur < nr; ++cur) {
-        // bring the remaining list back to its initial (reversed) order
-        for (int e = lane; e < nundo; e += 64) {
-            const int2 w = undo[e];
-            remaining[w.x] = nc - 1 - w.x;
-            pos[w.y] = nc - 1 - w.y;
-        }
-        nundo = 0;
-#pragma unroll
-        for (int k = 0; k < NCOL; ++k) spc[k] = INF;
         unsigned sc = 0;            // own columns already scanned (in the tree)
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
-        __syncthreads();
 
         while (true) {
+#ifdef DM_LAP_STAMPS
+            st_t = __builtin_amdgcn_s_memtime();
+#endif
             const double ui = u[i];
-            const int jl = __builtin_amdgcn_readfirstlane(remaining[n > 0 ? n - 1 : 0]);  // column at the last position
             const bool in_lds = i < R;
-            const bool first_touch = (i == cur) && !in_lds;   // row `cur` is read in full exactly here
             const unsigned live = valid & ~sc;
+            float c[NCOL];
+            if (in_lds) {
+                const float *row = crow + i * nc;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+            } else {
+                const float *row = cg + (size_t)i * qs;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+                if (i == cur) {     // the only full read of a row that is not resident: validate it here
+                    bool badrow = false;
+#pragma unroll
+                    for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
+                    if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
+                }
+            }
             double lmin = INF;
-            bool badrow = false;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const int j = lane + 64 * k;
-                float c = 0.0f;
-                if ((valid >> k) & 1u) c = in_lds ? crow[i * nc + j] : cg[(size_t)i * qs + j];
-                if (first_touch) badrow |= cost_is_invalid(c);
-                const double r = ((min_val + (double)c) - ui) - v[k];
+                const double r = ((min_val + (double)c[k]) - ui) - v[k];
                 const bool lv = (live >> k) & 1u;
                 const bool better = lv && (r < spc[k]);
                 spc[k] = better ? r : spc[k];
                 pth[k] = better ? i : pth[k];
                 lmin = lv ? fmin(lmin, spc[k]) : lmin;
             }
-            if (first_touch && __any(badrow)) {
-                if (lane == 0) dm::raise_status(status, DM_ST_INVALID_COST);
-                return;
-            }
-            const double m = dm::wave_min_f64(lmin);
-            if (!(m < INF)) {
-                if (lane == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
-                return;
-            }
-
-            // which column attains the minimum
-            int cnt = 0, cj = -1, cr = -1;
+            DM_STAMP(0)
+            const double wm = dm::wave_min_f64(lmin);
+            DM_STAMP(1)
+            // the wave's candidate under the list-position rule
+            unsigned key = 0;
+            int cj = -1, cr = -1;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const bool hit = ((live >> k) & 1u) && (spc[k] == m);
-                cnt += hit ? 1 : 0;
-                cj = hit ? lane + 64 * k : cj;
-                cr = hit ? r4c[k] : cr;
+                const bool hit = ((live >> k) & 1u) && (spc[k] == wm);
+                const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
+                if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
             }
-            const unsigned long long has = __ballot(cnt > 0);
-            const unsigned long long multi = __ballot(cnt > 1);
-            int jw, rw, pw;
-            if (__popcll(has) == 1 && multi == 0) {
-                const int wl = __ffsll((long long)has) - 1;
-                jw = dm::readlane_i32(cj, wl);
-                rw = dm::readlane_i32(cr, wl);
-                pw = __builtin_amdgcn_readfirstlane(pos[jw]);
-            } else {
-                // several columns tie: apply the list-position rule
-                unsigned key = 0;
-                cj = -1; cr = -1;
-#pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
-                    const bool hit = ((live >> k) & 1u) && (spc[k] == m);
-                    if (hit) {
-                        const int j = lane + 64 * k;
-                        const int pp = pos[j];
-                        const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + pp) : (unsigned)(nc - pp);
-                        if (kk > key) { key = kk; cj = j; cr = r4c[k]; }
-                    }
-                }
-                const unsigned K = dm::wave_max_u32(key);
-                const unsigned long long win = __ballot(key == K);
-                const int wl = __ffsll((long long)win) - 1;
-                jw = dm::readlane_i32(cj, wl);
-                rw = dm::readlane_i32(cr, wl);
-                pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
+            const unsigned wk = dm::wave_max_u32(key);
+            if (wk != 0 && key == wk) {     // exactly one lane: keys are unique
+                sval[par * 16 + wave] = wm;
+                skey[par * 16 + wave] = wk;
+                sj[par * 16 + wave] = cj;
+                sr[par * 16 + wave] = cr;
+            } else if (wk == 0 && lane == 0) {
+                sval[par * 16 + wave] = INF;
+                skey[par * 16 + wave] = 0;
             }
-            min_val = m;
+            DM_STAMP(2)
+            __syncthreads();
+            DM_STAMP(3)
+            const int sl = par * 16 + (lane < W ? lane : 0);
+            const double x = lane < W ? sval[sl] : INF;
+            unsigned kx = lane < W ? skey[sl] : 0u;
+            const double m = dm::wave_min_f64(x);
+            if (!(m < INF)) {
+                if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
+                return;
+            }
+            kx = (x == m) ? kx : 0u;
+            const unsigned K = dm::wave_max_u32(kx);
+            const int wv = __ffsll((long long)__ballot(kx == K && lane < W)) - 1;
+            const int jw = __builtin_amdgcn_readfirstlane(sj[par * 16 + wv]);
+            const int rw = __builtin_amdgcn_readfirstlane(sr[par * 16 + wv]);
+            const int pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
             // swap-with-last removal of column jw from the remaining list
+            const int jl = __builtin_amdgcn_readfirstlane(remaining[n - 1]);
             --n;
-            if (lane == 0) {
-                remaining[pw] = jl;
-                pos[jl] = pw;
-                undo[nundo] = make_int2(pw, jl);
+            if (tid == 0) remaining[pw] = jl;
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) {
+                const int j = tid + BS * k;
+                posr[k] = (j == jl) ? pw : posr[k];
+                if (j == jw) sc |= 1u << k;
             }
-            ++nundo;
-            if ((jw & 63) == lane) sc |= 1u << (jw >> 6);
+            par ^= 1;
+            DM_STAMP(4)
+#ifdef DM_LAP_STAMPS
+            ++st_iters;
+#endif
+            min_val = m;
             if (rw == -1) { sink = jw; break; }
             i = rw;
         }
@@ -224,16 +263,16 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 #pragma unroll
         for (int k = 0; k < NCOL; ++k) {
             if ((sc >> k) & 1u) {
-                const int j = lane + 64 * k;
+                const int j = tid + BS * k;
                 const double d = min_val - spc[k];
                 if (j != sink) u[r4c[k]] += d;
                 v[k] -= d;
                 pathL[j] = pth[k];
             }
         }
-        if (lane == 0) u[cur] += min_val;
+        if (tid == 0) u[cur] += min_val;
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             int j = sink;
             for (int guard = 0; guard <= nr; ++guard) {
                 const int ii = pathL[j];
@@ -245,17 +284,40 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
             }
         }
         __syncthreads();
+        // refresh the assignments that may have changed, put the list back in its initial order
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k)
-            if ((sc >> k) & 1u) r4c[k] = row4col[lane + 64 * k];
+        for (int k = 0; k < NCOL; ++k) {
+            const int j = tid + BS * k;
+            if ((sc >> k) & 1u) r4c[k] = row4col[j];
+            spc[k] = INF;
+            posr[k] = nc - 1 - j;
+            if ((valid >> k) & 1u) remaining[nc - 1 - j] = j;
+        }
+        // (the next step's first read of `remaining` follows that step's barrier)
     }
 
-    int64_t *so = src_out + set.out_off + t0;
-    int64_t *to = tgt_out + set.out_off + t0;
-    int base = 0;
-#pragma unroll
-    for (int k = 0; k < NCOL; ++k)
-        emit_pair(((valid >> k) & 1u) && r4c[k] >= 0, lane + 64 * k, r4c[k], base, lane, so, to);
+    __syncthreads();
+#ifdef DM_LAP_STAMPS
+    if (tid == 0) {
+        // diagnostic build: cycle stamps go to the tail of tgt_out's last set region (never read back as indices)
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(tgt_out) + (size_t)gridDim.x * 0;
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *rec = reinterpret_cast<unsigned long long *>(status + 16) + (size_t)blockIdx.x * 12;
+        rec[0] = st_c1 - st_c0; rec[1] = c2 - st_c1; rec[2] = r2 - st_r0; rec[3] = st_iters; rec[4] = nr; rec[5] = c2 - st_c0;
+        for (int q = 0; q < 5; ++q) rec[6 + q] = st_seg[q];
+        (void)dbg;
+    }
+#endif
+    if (wave == 0) {
+        int64_t *so = src_out + set.out_off + t0;
+        int64_t *to = tgt_out + set.out_off + t0;
+        int base = 0;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int j = j0 + lane;
+            const int r = j < nc ? row4col[j] : -1;
+            emit_pair(r >= 0, j, r, base, lane, so, to);
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, const int S,
@@ -277,7 +339,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
     const int T = tgt_off[b + 1] - t0;
     if (T == 0) return;
     const bool transposed = T < Q;        // scipy transposes when the matrix has more rows (queries) than columns
-    if (!all_problems && transposed && Q <= FAST_MAX_Q) return;   // lap_wave_kernel's problem
+    if (!all_problems && transposed && Q <= FAST_MAX_Q) return;   // lap_block_kernel's problem
     const int nr = transposed ? T : Q;
     const int nc = transposed ? Q : T;
 
@@ -379,29 +441,64 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
     }
 }
 
-int ncol_class(int Q)
+// (NCOL, W) of the workgroup that solves problems with Q queries when P problems are in flight.
+// Few problems: as many wavefronts per problem as there are 64-column slices (latency);
+// many problems: fewer, fatter wavefronts so that the grid fits the chip in few rounds.
+constexpr int NCOL_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 15, FAST_MAX_NCOL};
+
+void pick_shape(int Q, long long P, int *ncol, int *waves)
 {
-    static const int classes[] = {2, 5, 10, 15, FAST_MAX_NCOL};
-    for (int c : classes) if (Q <= 64 * c) return c;
-    return 0;
+    const int need = (Q + 63) / 64;                    // 64-column slices
+    long long w = need;
+    const long long wave_budget = 6144;                // about 24 wavefronts per CU
+    if (P * need > wave_budget) w = wave_budget / P;
+    if (w > 16) w = 16;
+    if (w < 1) w = 1;
+    int n = (need + (int)w - 1) / (int)w;
+    for (int c : NCOL_CLASSES) if (c >= n) { n = c; break; }
+    *ncol = n;
+    *waves = (need + n - 1) / n;
 }
 
 template <int NCOL>
-int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
-                int32_t *status, hipStream_t st)
+int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *cost, const int32_t *tgt_off,
+                 const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
+                 int32_t *status, hipStream_t st)
 {
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
-    const size_t fixed = (size_t)t_cap * (8 + 8 + 4) + (size_t)4 * 64 * NCOL * 4;
+    const int qcap = 64 * waves * NCOL;
+    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * (8 + 4 + 4 + 4) + (size_t)3 * qcap * 4;
     size_t want = (size_t)fast_T * max_Q * sizeof(float);
-    const size_t budget = 64 * 1024;
-    if (fixed >= budget) return DM_E_UNSUPPORTED;
+    // few problems: two workgroups per CU can share the 160 KB of LDS; many: keep more resident
+    const size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : 48 * 1024;
+    if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
-    hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * B), dim3(64), fixed + want, st, arr, n, cost,
-                       tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
-    return dm::check_hip(hipGetLastError(), "lap_wave_kernel launch");
+    static bool big_lds_enabled = false;
+    if (fixed + want > 64 * 1024 && !big_lds_enabled) {
+        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_block_kernel<NCOL>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
+                               "hipFuncSetAttribute(lap_block_kernel)");
+        if (rc != DM_OK) return rc;
+        big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(lap_block_kernel<NCOL>, dim3((unsigned)n * B), dim3(64 * waves), fixed + want, st, arr, n,
+                       cost, tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
+    return dm::check_hip(hipGetLastError(), "lap_block_kernel launch");
+}
+
+int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, const float *cost,
+                     const int32_t *tgt_off, const int32_t *order, int max_T, int max_Q, int64_t *src_out,
+                     int64_t *tgt_out, int32_t *status, hipStream_t st)
+{
+#define DM_CASE(N) case N: return launch_block<N>(arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st)
+    switch (ncol) {
+        DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
+        DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
+    }
+#undef DM_CASE
+    return DM_E_INVALID_ARG;
 }
 
 }  // namespace
@@ -426,27 +523,25 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
         if (needs_generic && (Q > GENERIC_MAX || max_T > GENERIC_MAX)) return DM_E_UNSUPPORTED;
     }
 
-    static const int classes[] = {2, 5, 10, 15, FAST_MAX_NCOL};
     if (!g_force_generic) {
-        for (int cls : classes) {
+        // one launch per distinct Q among the sets the register kernel can take
+        bool done[4096] = {false};
+        for (int s0 = 0; s0 < S; ++s0) {
+            const int Q = sets[s0].Q;
+            if (done[s0] || Q > FAST_MAX_Q) continue;
+            int total = 0;
+            for (int s = s0; s < S; ++s) total += (!done[s] && sets[s].Q == Q) ? 1 : 0;
+            int ncol, waves;
+            pick_shape(Q, (long long)total * B, &ncol, &waves);
             DmSetArray arr;
-            int n = 0, max_Q = 0;
-            for (int s = 0; s <= S; ++s) {
-                if (s < S && ncol_class(sets[s].Q) == cls) {
-                    arr.s[n++] = sets[s];
-                    if (sets[s].Q > max_Q) max_Q = sets[s].Q;
-                }
+            int n = 0;
+            for (int s = s0; s <= S; ++s) {
+                if (s < S && !done[s] && sets[s].Q == Q) { arr.s[n++] = sets[s]; done[s] = true; }
                 if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
-                    int rc;
-                    switch (cls) {
-                    case 2: rc = launch_wave<2>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st); break;
-                    case 5: rc = launch_wave<5>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st); break;
-                    case 10: rc = launch_wave<10>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st); break;
-                    case 15: rc = launch_wave<15>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st); break;
-                    default: rc = launch_wave<FAST_MAX_NCOL>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st); break;
-                    }
+                    int rc = launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, src_out,
+                                              tgt_out, status, st);
                     if (rc != DM_OK) return rc;
-                    n = 0; max_Q = 0;
+                    n = 0;
                 }
             }
         }
