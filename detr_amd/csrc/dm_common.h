@@ -69,6 +69,26 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x)
     return (unsigned)__builtin_amdgcn_readlane(v, 63);
 }
 
+// Minimum of an unsigned over the wave, wave-uniform result.  Lanes without a DPP source take
+// the identity, which lets the compiler fold each step into one v_min_u32 with a DPP operand.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_step(unsigned x)
+{
+    const unsigned y = (unsigned)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)x, CTRL, ROW_MASK, 0xF, false);
+    return min(x, y);
+}
+
+__device__ __forceinline__ unsigned wave_min_u32(unsigned x)
+{
+    x = dpp_min_step<DPP_QUAD_SWAP1, 0xF>(x);
+    x = dpp_min_step<DPP_QUAD_SWAP2, 0xF>(x);
+    x = dpp_min_step<DPP_ROW_SHR4, 0xF>(x);
+    x = dpp_min_step<DPP_ROW_SHR8, 0xF>(x);
+    x = dpp_min_step<DPP_ROW_BCAST15, 0xA>(x);
+    x = dpp_min_step<DPP_ROW_BCAST31, 0xC>(x);
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 __device__ __forceinline__ int readlane_i32(int v, int lane)
 {
     return __builtin_amdgcn_readlane(v, lane);

@@ -11,14 +11,18 @@
 //     among the remaining columns of minimal reduced cost, take the unassigned one at
 //     the LARGEST list position if there is one, else the one at the SMALLEST position.
 //
-// One workgroup solves one (set, image) problem; there is no inter-workgroup traffic.
-//   lap_block_kernel<NCOL> T < Q <= 1088: a workgroup of 1..16 wavefronts per problem; every
-//                          thread owns NCOL columns (queries) and keeps their reduced cost,
-//                          dual, assignment and predecessor in registers; column minima are
-//                          DPP wave reductions combined through LDS; the first rows of the
+// One wavefront solves one (set, image) problem; there is no inter-workgroup traffic.
+//   lap_wave_kernel<NCOL>  T < Q <= 64*NCOL <= 1088: one wavefront per problem; every lane
+//                          owns NCOL columns (queries) and keeps their reduced cost, dual,
+//                          assignment and predecessor in registers; the column minimum is
+//                          located with 32-bit DPP wave reductions; the first rows of the
 //                          cost block are staged in LDS by LDS-DMA.
 //   lap_generic_kernel     any shape up to 4096 x 4096 (also T >= Q, where scipy does
 //                          not transpose): literal list-order scan with all state in LDS.
+#include <initializer_list>
+#include <type_traits>
+#include <utility>
+
 #include "dm_common.h"
 
 namespace dm {
@@ -32,7 +36,22 @@ constexpr int FAST_MAX_NCOL = 17;
 constexpr int FAST_MAX_Q = 64 * FAST_MAX_NCOL;
 constexpr int GENERIC_MAX = 4096;
 
-int g_force_generic = 0;
+int g_lap_mode = 0;   // 0: automatic; 1: list-order kernel only; 2: workgroup kernel; 3: wavefront kernel
+
+// Diagnostic build only (-DDM_LAP_STAMPS): cycle stamps around the segments of a step.
+#ifdef DM_LAP_STAMPS
+#define DM_STAMP(idx)                                                                              \
+    {                                                                                              \
+        unsigned long long t_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st_seg[idx] += t_ - st_t;                                                                  \
+        st_t = t_;                                                                                 \
+    }
+#else
+#define DM_STAMP(idx)
+#endif
 
 __device__ __forceinline__ bool cost_is_invalid(float c)
 {
@@ -52,6 +71,328 @@ __device__ __forceinline__ void emit_pair(bool has, int query, int target, int &
         tgt[o] = target;
     }
     base += __popcll(bal);
+}
+
+// Calls f(std::integral_constant<int, K>) for the K in [0, N) equal to the wave-uniform k:
+// a register array can then be indexed by a run-time (but uniform) k without leaving registers.
+template <typename F, int... Is>
+__device__ __forceinline__ void with_static_index(int k, F &&f, std::integer_sequence<int, Is...>)
+{
+    (void)std::initializer_list<int>{((k == Is) ? (f(std::integral_constant<int, Is>{}), 0) : 0)...};
+}
+
+// Order-preserving map of a double's high/low words to unsigned integers.
+__device__ __forceinline__ void sortable_words(double x, unsigned &hi, unsigned &lo)
+{
+    const int h = __double2hiint(x);
+    const unsigned m = (unsigned)(h >> 31);          // all ones for negative values
+    hi = (unsigned)h ^ (m | 0x80000000u);
+    lo = (unsigned)__double2loint(x) ^ m;
+}
+
+// One wavefront per problem with T < Q <= 64*NCOL.  Lane l owns the columns (queries)
+// j = l + 64*k, k < NCOL, and keeps their reduced cost, dual, assignment and predecessor in
+// registers.  A column that has been scanned (or lies past Q) is parked with reduced cost +inf
+// and dual -inf, which makes it inert in the scan without a mask test; its real values wait in
+// a shadow register pair until the row's dual update.  Per Dijkstra step the minimum is located
+// with 32-bit DPP reductions on the order-preserving high word (low word and list-position tie
+// key only when needed).  No barrier: a single wave executes its LDS operations in order.
+template <int NCOL>
+__global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, const int S,
+                                                       const float *__restrict__ cost,
+                                                       const int32_t *__restrict__ tgt_off,
+                                                       const int32_t *__restrict__ order,
+                                                       int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
+                                                       int32_t *status, const int t_cap, const int lds_cost_floats)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    using KSeq = std::make_integer_sequence<int, NCOL>;
+    constexpr int QCAP = 64 * NCOL;
+    constexpr double NEG_INF = -INF;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x % S;
+    const int bi = blockIdx.x / S;
+    const int b = order ? order[bi] : bi;
+    const DmSet &set = sets.s[s];
+    const int nc = set.Q;                 // columns = queries
+    const int t0 = tgt_off[b];
+    const int nr = tgt_off[b + 1] - t0;   // rows = targets
+    if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
+#ifdef DM_LAP_STAMPS
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_c1 = 0;
+    int st_iters = 0;
+    unsigned long long st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+#endif
+
+    double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
+    int *col4row = reinterpret_cast<int *>(u + t_cap);      // [t_cap]
+    int *sclist = col4row + t_cap;                          // [t_cap] columns scanned in the current row, in order
+    int *row4col = sclist + t_cap;                          // [QCAP]
+    int *pathL = row4col + QCAP;                            // [QCAP]
+    int *remaining = pathL + QCAP;                          // [QCAP] list position -> column
+    int *pos = remaining + QCAP;                            // [QCAP] column -> list position
+    float *crow = reinterpret_cast<float *>(pos + QCAP);    // [lds_cost_floats] first rows of the block
+
+    const int qs = set.q_stride;
+    const float *cg = cost + set.cost_off + (size_t)t0 * qs;
+    const int R = min(nr, lds_cost_floats / nc);            // rows resident in LDS
+
+    double v[NCOL], spc[NCOL], v_real[NCOL], spc_real[NCOL];
+    int r4c[NCOL], pth[NCOL], jc[NCOL];
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) {
+        const int j = lane + 64 * k;
+        const bool ok = j < nc;
+        v[k] = ok ? 0.0 : NEG_INF;
+        spc[k] = INF; v_real[k] = 0.0; spc_real[k] = INF; r4c[k] = -1; pth[k] = -1;
+        jc[k] = min(j, nc - 1);      // columns past the end alias the last one and stay parked
+        if (ok) {
+            row4col[j] = -1;
+            remaining[nc - 1 - j] = j;
+            pos[j] = nc - 1 - j;
+        }
+    }
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+
+    // Stage the first R rows in LDS.  A dense, 16-byte aligned block goes through LDS-DMA
+    // (no registers, every piece in flight at once); anything else through registers.
+    const int nfl = R * nc;
+    bool bad = false;
+    if (qs == nc && (nc & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0) {
+        for (int base = 0; base < nfl; base += 256) {
+            const int e = base + lane * 4;
+            if (e < nfl)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(cg + e),
+                                                 (__attribute__((address_space(3))) void *)(crow + base), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int e = lane * 4; e < nfl; e += 256) {
+            const float4 x = *reinterpret_cast<const float4 *>(crow + e);
+            bad |= cost_is_invalid(x.x) | cost_is_invalid(x.y) | cost_is_invalid(x.z) | cost_is_invalid(x.w);
+        }
+    } else {
+        for (int i = 0; i < R; ++i) {
+            float c[NCOL];
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) c[k] = cg[(size_t)i * qs + jc[k]];
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) {
+                bad |= cost_is_invalid(c[k]);
+                crow[i * nc + jc[k]] = c[k];
+            }
+        }
+    }
+    if (__any(bad)) {
+        if (lane == 0) dm::raise_status(status, DM_ST_INVALID_COST);
+        return;
+    }
+    __syncthreads();
+#ifdef DM_LAP_STAMPS
+    st_c1 = __builtin_amdgcn_s_memtime();
+#endif
+
+    for (int cur = 0; cur < nr; ++cur) {
+        double min_val = 0.0;
+        int i = cur, n = nc, sink = -1;
+
+        while (n > 0) {      // every step parks one column: at most nc steps
+#ifdef DM_LAP_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
+#endif
+            const double ui = u[i];
+            const int jl = __builtin_amdgcn_readfirstlane(remaining[n - 1]);   // column at the last list position
+            float c[NCOL];
+            if (i < R) {
+                const float *row = crow + i * nc;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+            } else {
+                const float *row = cg + (size_t)i * qs;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+                if (i == cur) {     // the only full read of a row that is not resident: validate it here
+                    bool badrow = false;
+#pragma unroll
+                    for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
+                    if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
+                }
+            }
+            DM_STAMP(0)
+            double lmin = INF;
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) {
+                const double r = ((min_val + (double)c[k]) - ui) - v[k];   // +inf for parked columns
+                const bool better = r < spc[k];
+                spc[k] = better ? r : spc[k];
+                pth[k] = better ? i : pth[k];
+                lmin = fmin(lmin, spc[k]);
+            }
+            DM_STAMP(1)
+            // locate the minimum: high word, then (if several lanes share it) low word
+            unsigned hi, lo;
+            sortable_words(lmin, hi, lo);
+            const unsigned mhi = dm::wave_min_u32(hi);
+            bool mine = hi == mhi;
+            unsigned long long at = __ballot(mine);
+            if (__popcll(at) > 1) {
+                const unsigned mlo = dm::wave_min_u32(mine ? lo : 0xFFFFFFFFu);
+                mine = mine && (lo == mlo);
+                at = __ballot(mine);
+            }
+            const int wl0 = __ffsll((long long)at) - 1;
+            const double m = __hiloint2double(dm::readlane_i32(__double2hiint(lmin), wl0),
+                                              dm::readlane_i32(__double2loint(lmin), wl0));
+            if (!(m < INF)) {
+                if (lane == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
+                return;
+            }
+            DM_STAMP(2)
+            // columns attaining it
+            int hits = 0, cj = -1, cr = -1;
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) {
+                const bool hit = spc[k] == m;
+                hits += __popcll(__ballot(hit));
+                cj = hit ? lane + 64 * k : cj;
+                cr = hit ? r4c[k] : cr;
+            }
+            int jw, rw, pw;
+            if (hits == 1) {
+                jw = dm::readlane_i32(cj, wl0);
+                rw = dm::readlane_i32(cr, wl0);
+                pw = __builtin_amdgcn_readfirstlane(pos[jw]);
+            } else {
+                // several columns tie: the list-position rule decides
+                unsigned key = 0;
+                cj = -1; cr = -1;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) {
+                    if (spc[k] == m) {
+                        const int j = lane + 64 * k;
+                        const int pp = pos[j];
+                        const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + pp) : (unsigned)(nc - pp);
+                        if (kk > key) { key = kk; cj = j; cr = r4c[k]; }
+                    }
+                }
+                const unsigned K = dm::wave_max_u32(key);
+                const int wl = __ffsll((long long)__ballot(key == K)) - 1;
+                jw = dm::readlane_i32(cj, wl);
+                rw = dm::readlane_i32(cr, wl);
+                pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
+            }
+            DM_STAMP(3)
+            min_val = m;
+            // swap-with-last removal of column jw from the list
+            if (lane == 0) {
+                remaining[pw] = jl;
+                pos[jl] = pw;
+                sclist[nc - n] = jw;
+            }
+            --n;
+            // park the column in its owner's registers
+            with_static_index(jw >> 6, [&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (lane == (jw & 63)) {
+                    spc_real[K] = spc[K]; v_real[K] = v[K];
+                    spc[K] = INF; v[K] = NEG_INF;
+                }
+            }, KSeq{});
+            DM_STAMP(4)
+#ifdef DM_LAP_STAMPS
+            ++st_iters;
+#endif
+            if (rw == -1) { sink = jw; break; }
+            i = rw;
+        }
+
+        if (sink < 0) {      // ran out of columns without reaching an unassigned one
+            if (lane == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
+            return;
+        }
+        // Row end: dual update of the scanned columns, augmentation along the predecessor
+        // chain, un-parking, and the list back in its initial (reversed) order.
+        const int nsc = nc - n;
+        if (nsc == 1) {
+            // the first step already found an unassigned column: nothing changes but u[cur]
+            with_static_index(sink >> 6, [&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (lane == (sink & 63)) { r4c[K] = cur; v[K] = v_real[K]; }
+            }, KSeq{});
+            if (lane == 0) {
+                u[cur] += min_val;
+                col4row[cur] = sink;
+                row4col[sink] = cur;
+                // undo the single removal: column 0 (initially last) had moved into sink's slot
+                const int p0 = nc - 1 - sink;
+                remaining[nc - 1] = 0; pos[0] = nc - 1;
+                remaining[p0] = sink; pos[sink] = p0;
+            }
+        } else {
+            for (int e = 0; e < nsc; ++e) {
+                const int j = __builtin_amdgcn_readfirstlane(sclist[e]);
+                with_static_index(j >> 6, [&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    if (lane == (j & 63)) {
+                        const double d = min_val - spc_real[K];
+                        if (j != sink) u[r4c[K]] += d;
+                        v[K] = v_real[K] - d;
+                        pathL[j] = pth[K];
+                    }
+                }, KSeq{});
+            }
+            if (lane == 0) u[cur] += min_val;
+            __syncthreads();
+            if (lane == 0) {
+                int j = sink;
+                for (int guard = 0; guard <= nr; ++guard) {
+                    const int ii = pathL[j];
+                    row4col[j] = ii;
+                    const int jn = col4row[ii];
+                    col4row[ii] = j;
+                    j = jn;
+                    if (ii == cur) break;
+                }
+            }
+            __syncthreads();
+            for (int e = 0; e < nsc; ++e) {
+                const int j = __builtin_amdgcn_readfirstlane(sclist[e]);
+                with_static_index(j >> 6, [&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    if (lane == (j & 63)) r4c[K] = row4col[j];
+                }, KSeq{});
+            }
+            // Every list slot that changed is either the initial slot of a scanned column or one
+            // of the last nsc slots; both loops write initial values, overlaps agree.
+            for (int e = lane; e < nsc; e += 64) {
+                const int j = sclist[e];
+                remaining[nc - 1 - j] = j;
+                pos[j] = nc - 1 - j;
+            }
+            for (int e = n + lane; e < nc; e += 64) {
+                remaining[e] = nc - 1 - e;
+                pos[nc - 1 - e] = e;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) spc[k] = INF;
+    }
+
+#ifdef DM_LAP_STAMPS
+    if (lane == 0) {
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *rec = reinterpret_cast<unsigned long long *>(status + 16) + (size_t)blockIdx.x * 12;
+        rec[0] = st_c1 - st_c0; rec[1] = c2 - st_c1; rec[2] = r2 - st_r0; rec[3] = st_iters; rec[4] = nr; rec[5] = c2 - st_c0;
+        for (int q = 0; q < 5; ++q) rec[6 + q] = st_seg[q];
+    }
+#endif
+    int64_t *so = src_out + set.out_off + t0;
+    int64_t *to = tgt_out + set.out_off + t0;
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NCOL; ++k) emit_pair(r4c[k] >= 0, lane + 64 * k, r4c[k], base, lane, so, to);
 }
 
 // One workgroup of W wavefronts (W = blockDim.x / 64, 1..16) per problem with T < Q <= 64*W*NCOL.
@@ -82,15 +423,6 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
     const int t0 = tgt_off[b];
     const int nr = tgt_off[b + 1] - t0;   // rows = targets
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
-#ifdef DM_LAP_STAMPS
-    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long st_c1 = 0;
-    int st_iters = 0;
-    unsigned long long st_seg[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_n = 0;
-#define DM_STAMP(idx) { st_n = __builtin_amdgcn_s_memtime(); st_seg[idx] += st_n - st_t; st_t = st_n; }
-#else
-#define DM_STAMP(idx)
-#endif
 
     double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
     double *sval = u + t_cap;                               // [2][16] published wave minima
@@ -158,9 +490,6 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
         return;
     }
 
-#ifdef DM_LAP_STAMPS
-    st_c1 = __builtin_amdgcn_s_memtime();
-#endif
     int par = 0;
     for (int cur = 0; cur < nr; ++cur) {
         unsigned sc = 0;            // own columns already scanned (in the tree)
@@ -168,9 +497,6 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
         int i = cur, n = nc, sink = -1;
 
         while (true) {
-#ifdef DM_LAP_STAMPS
-            st_t = __builtin_amdgcn_s_memtime();
-#endif
             const double ui = u[i];
             const bool in_lds = i < R;
             const unsigned live = valid & ~sc;
@@ -200,9 +526,7 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
                 pth[k] = better ? i : pth[k];
                 lmin = lv ? fmin(lmin, spc[k]) : lmin;
             }
-            DM_STAMP(0)
             const double wm = dm::wave_min_f64(lmin);
-            DM_STAMP(1)
             // the wave's candidate under the list-position rule
             unsigned key = 0;
             int cj = -1, cr = -1;
@@ -222,9 +546,7 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
                 sval[par * 16 + wave] = INF;
                 skey[par * 16 + wave] = 0;
             }
-            DM_STAMP(2)
             __syncthreads();
-            DM_STAMP(3)
             const int sl = par * 16 + (lane < W ? lane : 0);
             const double x = lane < W ? sval[sl] : INF;
             unsigned kx = lane < W ? skey[sl] : 0u;
@@ -250,10 +572,6 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
                 if (j == jw) sc |= 1u << k;
             }
             par ^= 1;
-            DM_STAMP(4)
-#ifdef DM_LAP_STAMPS
-            ++st_iters;
-#endif
             min_val = m;
             if (rw == -1) { sink = jw; break; }
             i = rw;
@@ -297,17 +615,6 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
     }
 
     __syncthreads();
-#ifdef DM_LAP_STAMPS
-    if (tid == 0) {
-        // diagnostic build: cycle stamps go to the tail of tgt_out's last set region (never read back as indices)
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(tgt_out) + (size_t)gridDim.x * 0;
-        const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long *rec = reinterpret_cast<unsigned long long *>(status + 16) + (size_t)blockIdx.x * 12;
-        rec[0] = st_c1 - st_c0; rec[1] = c2 - st_c1; rec[2] = r2 - st_r0; rec[3] = st_iters; rec[4] = nr; rec[5] = c2 - st_c0;
-        for (int q = 0; q < 5; ++q) rec[6 + q] = st_seg[q];
-        (void)dbg;
-    }
-#endif
     if (wave == 0) {
         int64_t *so = src_out + set.out_off + t0;
         int64_t *to = tgt_out + set.out_off + t0;
@@ -339,7 +646,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
     const int T = tgt_off[b + 1] - t0;
     if (T == 0) return;
     const bool transposed = T < Q;        // scipy transposes when the matrix has more rows (queries) than columns
-    if (!all_problems && transposed && Q <= FAST_MAX_Q) return;   // lap_block_kernel's problem
+    if (!all_problems && transposed && Q <= FAST_MAX_Q) return;   // lap_wave_kernel's problem
     const int nr = transposed ? T : Q;
     const int nc = transposed ? Q : T;
 
@@ -441,11 +748,57 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
     }
 }
 
+constexpr int NCOL_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 15, FAST_MAX_NCOL};
+
+int ncol_class(int Q)
+{
+    for (int c : NCOL_CLASSES) if (Q <= 64 * c) return c;
+    return 0;
+}
+
+template <int NCOL>
+int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
+                const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
+                int32_t *status, hipStream_t st)
+{
+    const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
+    const int t_cap = (fast_T + 3) & ~3;
+    const size_t fixed = (size_t)t_cap * (8 + 4 + 4) + (size_t)4 * 64 * NCOL * 4;
+    size_t want = (size_t)fast_T * max_Q * sizeof(float);
+    // few problems: two workgroups per CU can share the 160 KB of LDS; many: keep more resident
+    const size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : 40 * 1024;
+    if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
+    if (fixed + want > budget) want = budget - fixed;
+    want &= ~(size_t)15;
+    static bool big_lds_enabled = false;
+    if (fixed + want > 64 * 1024 && !big_lds_enabled) {
+        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_wave_kernel<NCOL>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
+                               "hipFuncSetAttribute(lap_wave_kernel)");
+        if (rc != DM_OK) return rc;
+        big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * B), dim3(64), fixed + want, st, arr, n, cost,
+                       tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
+    return dm::check_hip(hipGetLastError(), "lap_wave_kernel launch");
+}
+
+int launch_wave_dyn(int ncol, const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
+                    const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
+                    int32_t *status, hipStream_t st)
+{
+#define DM_CASE(N) case N: return launch_wave<N>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st)
+    switch (ncol) {
+        DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
+        DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
+    }
+#undef DM_CASE
+    return DM_E_INVALID_ARG;
+}
+
 // (NCOL, W) of the workgroup that solves problems with Q queries when P problems are in flight.
 // Few problems: as many wavefronts per problem as there are 64-column slices (latency);
 // many problems: fewer, fatter wavefronts so that the grid fits the chip in few rounds.
-constexpr int NCOL_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 15, FAST_MAX_NCOL};
-
 void pick_shape(int Q, long long P, int *ncol, int *waves)
 {
     const int need = (Q + 63) / 64;                    // 64-column slices
@@ -503,9 +856,10 @@ int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, c
 
 }  // namespace
 
-// Testing aid: route every problem through the list-order kernel (non-zero) or restore
-// the default split between the two kernels (zero).
-extern "C" void dm_debug_force_generic_lap(int on) { g_force_generic = on; }
+// Testing aid: 0 restores the automatic choice of assignment kernel, 1 routes every problem
+// through the list-order kernel, 2 / 3 force the workgroup / wavefront register kernel for
+// the problems they can take.
+extern "C" void dm_debug_force_generic_lap(int mode) { g_lap_mode = mode; }
 
 extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
                           const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out,
@@ -519,11 +873,11 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
     for (int s = 0; s < S; ++s) {
         const int Q = sets[s].Q;
         if (Q < 1 || sets[s].q_stride < Q) return DM_E_INVALID_ARG;
-        const bool needs_generic = g_force_generic || Q > FAST_MAX_Q || max_T >= Q;
+        const bool needs_generic = (g_lap_mode == 1) || Q > FAST_MAX_Q || max_T >= Q;
         if (needs_generic && (Q > GENERIC_MAX || max_T > GENERIC_MAX)) return DM_E_UNSUPPORTED;
     }
 
-    if (!g_force_generic) {
+    if (!(g_lap_mode == 1)) {
         // one launch per distinct Q among the sets the register kernel can take
         bool done[4096] = {false};
         for (int s0 = 0; s0 < S; ++s0) {
@@ -531,15 +885,22 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
             if (done[s0] || Q > FAST_MAX_Q) continue;
             int total = 0;
             for (int s = s0; s < S; ++s) total += (!done[s] && sets[s].Q == Q) ? 1 : 0;
-            int ncol, waves;
-            pick_shape(Q, (long long)total * B, &ncol, &waves);
+            // few problems: a workgroup of several wavefronts per problem (latency); many: one
+            // wavefront per problem (throughput)
+            int ncol = ncol_class(Q), waves = 1;
+            const long long P = (long long)total * B;
+            const bool use_block = g_lap_mode == 2 || (g_lap_mode == 0 && P * ((Q + 63) / 64) <= 6144 * 4);
+            if (use_block) pick_shape(Q, P, &ncol, &waves);
             DmSetArray arr;
             int n = 0;
             for (int s = s0; s <= S; ++s) {
                 if (s < S && !done[s] && sets[s].Q == Q) { arr.s[n++] = sets[s]; done[s] = true; }
                 if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
-                    int rc = launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, src_out,
-                                              tgt_out, status, st);
+                    int rc = use_block
+                                 ? launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, src_out,
+                                                    tgt_out, status, st)
+                                 : launch_wave_dyn(ncol, arr, n, B, cost, tgt_off, order, max_T, Q, src_out, tgt_out,
+                                                   status, st);
                     if (rc != DM_OK) return rc;
                     n = 0;
                 }
@@ -551,7 +912,7 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
     DmSetArray arr;
     int n = 0, max_Q = 0;
     for (int s = 0; s <= S; ++s) {
-        if (s < S && (g_force_generic || sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q)) {
+        if (s < S && ((g_lap_mode == 1) || sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q)) {
             arr.s[n++] = sets[s];
             if (sets[s].Q > max_Q) max_Q = sets[s].Q;
         }
@@ -569,7 +930,7 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
                 if (rc != DM_OK) return rc;
             }
             hipLaunchKernelGGL(lap_generic_kernel, dim3((unsigned)n * B), dim3(64), lds, st, arr, n, cost, tgt_off,
-                               order, src_out, tgt_out, status, c_cap, r_cap, g_force_generic ? 1 : 0);
+                               order, src_out, tgt_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0);
             int rc = dm::check_hip(hipGetLastError(), "lap_generic_kernel launch");
             if (rc != DM_OK) return rc;
             n = 0; max_Q = 0;

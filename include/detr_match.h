@@ -128,8 +128,9 @@ int dm_match_f32(const DmSet *sets, int S, int B, int C,
 int dm_profile_enable(int on);
 int dm_profile_read(float *cost_ms, float *lap_ms);
 
-/* Testing aid: non-zero routes every assignment problem through the list-order kernel. */
-void dm_debug_force_generic_lap(int on);
+/* Testing aid: which assignment kernel takes the problems it can take.  0: automatic choice,
+ * 1: list-order kernel only, 2: workgroup-per-problem kernel, 3: wavefront-per-problem kernel. */
+void dm_debug_force_generic_lap(int mode);
 
 #ifdef __cplusplus
 }

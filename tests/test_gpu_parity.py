@@ -107,7 +107,7 @@ def _lsap_matrices(rng):
     return mats
 
 
-@pytest.mark.parametrize("force_generic", [0, 1])
+@pytest.mark.parametrize("force_generic", [0, 1, 2, 3])
 def test_lsap_bit_exact_vs_scipy(force_generic):
     import detr_amd
 
@@ -127,7 +127,7 @@ def test_lsap_bit_exact_vs_scipy(force_generic):
 def test_lsap_errors():
     import detr_amd
 
-    for force in (0, 1):
+    for force in (0, 1, 2, 3):
         detr_amd.lib.dm_debug_force_generic_lap(force)
         try:
             for bad in (np.nan, -np.inf):
