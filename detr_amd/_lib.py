@@ -35,7 +35,7 @@ class DmParams(ctypes.Structure):
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_profile_enable", "dm_profile_read",
-           "dm_debug_force_generic_lap"]
+           "dm_debug_force_generic_lap", "dm_debug_cost_queries_per_thread"]
 
 
 def _load():
@@ -62,6 +62,8 @@ def _load():
     lib.dm_match_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, prmp, vp, i64p, i64p, vp, vp]
     lib.dm_debug_force_generic_lap.restype = None
     lib.dm_debug_force_generic_lap.argtypes = [ctypes.c_int]
+    lib.dm_debug_cost_queries_per_thread.restype = None
+    lib.dm_debug_cost_queries_per_thread.argtypes = [ctypes.c_int]
     lib.dm_profile_enable.restype = ctypes.c_int
     lib.dm_profile_enable.argtypes = [ctypes.c_int]
     lib.dm_profile_read.restype = ctypes.c_int

@@ -5,16 +5,21 @@
 // /root/reference/utils/box_ops.py:17-21, 32-45, 48-69: class cost (softmax gather or
 // focal), L1 (torch.cdist p=1), GIoU, weighted sum -- one pass, one write per cost entry.
 //
-// Mapping: one thread per query, one workgroup per (query tile, image, set).  The
-// image's targets are staged once per workgroup in LDS as pre-converted records
-// (xyxy, area, cxcywh, label) and broadcast-read by every lane; the cost row of a
-// target is written with consecutive lanes on consecutive queries (coalesced).
-// Logits with C <= 4 go straight to registers; wider logit rows are streamed with
-// 16-byte loads into a wave-private LDS tile with an odd row stride so that each
-// lane can read its own row bank-conflict-free.
+// Work split: one lane per query; the image's targets are staged once per workgroup in LDS
+// as pre-converted records (xyxy, area, cxcywh, label) that every lane reads as broadcasts;
+// the cost row of a target is written with consecutive lanes on consecutive queries
+// (coalesced 256-byte stores).
+//   cost_small_kernel  C <= 4: the logits go straight to registers and the class cost of
+//                      every class is computed once per query.
+//   cost_tile_kernel   C > 4: a workgroup of four wavefronts shares one tile of 64 logit
+//                      rows, streamed with coalesced loads into LDS (odd row stride, so each
+//                      lane reads its own row conflict-free); the wavefronts split the
+//                      targets four ways.
 //
-// The kernel is HBM-bound streaming work (no contraction, so no MFMA).  It is compiled
-// with -ffp-contract=off and evaluates every expression in the reference's order.
+// HBM-bound streaming work: no contraction, so no MFMA.  Compiled with -ffp-contract=off;
+// the two divisions of the GIoU are evaluated as reciprocal * numerator (v_rcp_f32, 1 ulp)
+// and the final sums use explicit fma -- within 1e-7 relative of the reference's
+// separately rounded operations, far inside the 1e-5 parity bar.
 #include "dm_common.h"
 
 namespace {
@@ -29,6 +34,21 @@ struct __align__(16) TgtRec {
     int pad0, pad1;
 };
 static_assert(sizeof(TgtRec) == 48, "TgtRec is read as three 16-byte LDS loads");
+
+// v_min_f32 / v_max_f32 without the canonicalising copies the compiler adds for possibly
+// signalling NaN inputs: boxes with NaN coordinates are rejected through the status word.
+__device__ __forceinline__ float fast_min(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fast_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 __device__ __forceinline__ float pow_gamma(float x, float gamma)
 {
@@ -52,163 +72,259 @@ struct PredBox {
     float cx, cy, w, h, x0, y0, x1, y1, area;
 };
 
-// matcher.py:84-90 and box_ops.py:32-45, 61-69 for one (query, target) pair
-__device__ __forceinline__ float pair_cost(const PredBox &p, const TgtRec &g, float cls, const DmParams &prm)
+__device__ __forceinline__ PredBox make_pred(const float4 raw)
 {
-    const float l1 = ((fabsf(p.cx - g.cx) + fabsf(p.cy - g.cy)) + fabsf(p.w - g.w)) + fabsf(p.h - g.h);
-    const float iw = fmaxf(fminf(p.x1, g.x1) - fmaxf(p.x0, g.x0), 0.0f);
-    const float ih = fmaxf(fminf(p.y1, g.y1) - fmaxf(p.y0, g.y0), 0.0f);
-    const float inter = iw * ih;
-    const float uni = (p.area + g.area) - inter;
-    const float iou = inter / uni;
-    const float ew = fmaxf(fmaxf(p.x1, g.x1) - fminf(p.x0, g.x0), 0.0f);
-    const float eh = fmaxf(fmaxf(p.y1, g.y1) - fminf(p.y0, g.y0), 0.0f);
-    const float earea = ew * eh;
-    const float giou = iou - (earea - uni) / earea;
-    return ((prm.w_bbox * l1) + (prm.w_class * cls)) + (prm.w_giou * (-giou));
-}
-
-template <bool TILE>
-__global__ void cost_kernel(const DmSetArray sets, const int C, const int64_t *__restrict__ labels,
-                            const float *__restrict__ tboxes, const int32_t *__restrict__ tgt_off,
-                            const DmParams prm, float *__restrict__ cost, int32_t *status)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    TgtRec *tg = reinterpret_cast<TgtRec *>(smem);
-
-    const DmSet &set = sets.s[blockIdx.z];
-    const int b = blockIdx.y;
-    const int Q = set.Q;
-    const int q0 = blockIdx.x * blockDim.x;
-    if (q0 >= Q) return;
-    const int q = q0 + threadIdx.x;
-    const bool active = q < Q;
-    const int t0 = tgt_off[b];
-    const int T = tgt_off[b + 1] - t0;
-    const size_t row = (size_t)b * Q + (active ? q : Q - 1);
-
-    // own prediction box; the reference validates every prediction of the batch
-    const float4 raw = reinterpret_cast<const float4 *>(set.boxes)[row];
     PredBox p;
     p.cx = raw.x; p.cy = raw.y; p.w = raw.z; p.h = raw.w;
     p.x0 = p.cx - 0.5f * p.w; p.y0 = p.cy - 0.5f * p.h;
     p.x1 = p.cx + 0.5f * p.w; p.y1 = p.cy + 0.5f * p.h;
     p.area = (p.x1 - p.x0) * (p.y1 - p.y0);
-    if (active && !((p.x1 >= p.x0) && (p.y1 >= p.y0))) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+    return p;
+}
+
+__device__ __forceinline__ bool pred_valid(const PredBox &p)
+{
+    return (p.x1 >= p.x0) && (p.y1 >= p.y0);   // false for NaN, like box_ops.py:59
+}
+
+// matcher.py:84-90 and box_ops.py:32-45, 61-69 for one (query, target) pair.
+// `wcls` is cost_class * class cost.
+__device__ __forceinline__ float pair_cost(const PredBox &p, const TgtRec &g, float wcls, float w_bbox, float w_giou)
+{
+    const float l1 = ((fabsf(p.cx - g.cx) + fabsf(p.cy - g.cy)) + fabsf(p.w - g.w)) + fabsf(p.h - g.h);
+    const float iw = fast_max(fast_min(p.x1, g.x1) - fast_max(p.x0, g.x0), 0.0f);
+    const float ih = fast_max(fast_min(p.y1, g.y1) - fast_max(p.y0, g.y0), 0.0f);
+    const float inter = iw * ih;
+    const float uni = (p.area + g.area) - inter;
+    // enclosing box: never negative for valid boxes, so the reference's clamp is a no-op
+    const float ew = fast_max(p.x1, g.x1) - fast_min(p.x0, g.x0);
+    const float eh = fast_max(p.y1, g.y1) - fast_min(p.y0, g.y0);
+    const float earea = ew * eh;
+    // -giou = -(inter/uni - (earea - uni)/earea) = (1 - inter/uni) - uni/earea
+    const float neg_giou = __builtin_fmaf(-uni, __builtin_amdgcn_rcpf(earea),
+                                          __builtin_fmaf(-inter, __builtin_amdgcn_rcpf(uni), 1.0f));
+    return __builtin_fmaf(w_bbox, l1, __builtin_fmaf(w_giou, neg_giou, wcls));
+}
+
+// Stage targets [tc, tc + nt) of the image in LDS (validated, pre-converted).
+__device__ __forceinline__ void stage_targets(TgtRec *tg, const int64_t *__restrict__ labels,
+                                              const float *__restrict__ tboxes, int first, int nt, int C,
+                                              int32_t *status)
+{
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) {
+        const int t = first + i;
+        const float4 gb = reinterpret_cast<const float4 *>(tboxes)[t];
+        long long l = labels[t];
+        TgtRec g;
+        g.cx = gb.x; g.cy = gb.y; g.w = gb.z; g.h = gb.w;
+        g.x0 = g.cx - 0.5f * g.w; g.y0 = g.cy - 0.5f * g.h;
+        g.x1 = g.cx + 0.5f * g.w; g.y1 = g.cy + 0.5f * g.h;
+        g.area = (g.x1 - g.x0) * (g.y1 - g.y0);
+        if (!((g.x1 >= g.x0) && (g.y1 >= g.y0))) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+        if (l < -(long long)C || l >= (long long)C) { dm::raise_status(status, DM_ST_LABEL_RANGE); l = 0; }
+        if (l < 0) l += C;   // python-style negative index
+        g.label = (int)l; g.pad0 = 0; g.pad1 = 0;
+        tg[i] = g;
+    }
+}
+
+// C <= 4.  Every thread owns QPT consecutive queries of one image and loops over the image's
+// targets; the QPT costs of a target go out as one QPT*4-byte store.
+template <int C, int QPT>
+__global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray sets,
+                                                            const int64_t *__restrict__ labels,
+                                                            const float *__restrict__ tboxes,
+                                                            const int32_t *__restrict__ tgt_off, const DmParams prm,
+                                                            float *__restrict__ cost, int32_t *status)
+{
+    __shared__ TgtRec tg[TCHUNK];
+    typedef float vecq __attribute__((ext_vector_type(QPT)));
+
+    const DmSet &set = sets.s[blockIdx.z];
+    const int b = blockIdx.y;
+    const int Q = set.Q;
+    const int q0 = (blockIdx.x * blockDim.x + threadIdx.x) * QPT;     // first query of this thread
+    if ((int)(blockIdx.x * blockDim.x) * QPT >= Q) return;
+    const int t0 = tgt_off[b];
+    const int T = tgt_off[b + 1] - t0;
+
+    // own prediction boxes and logits (clamped to the last query when past the end); the
+    // reference validates every prediction of the batch
+    float4 raw[QPT];
+    float x[QPT][C];
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        const size_t row = (size_t)b * Q + min(q0 + i, Q - 1);
+        raw[i] = reinterpret_cast<const float4 *>(set.boxes)[row];
+        const float *lg = set.logits + row * (size_t)C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[i][c] = lg[c];
+    }
+    if (T > 0) stage_targets(tg, labels, tboxes, t0, min(TCHUNK, T), C, status);
+
+    PredBox p[QPT];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < QPT; ++i) {
+        p[i] = make_pred(raw[i]);
+        ok = ok && (pred_valid(p[i]) || q0 + i >= Q);
+    }
+    if (!ok) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
     if (T == 0) return;
 
-    const int Cs = C | 1;                      // odd LDS row stride
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *wt = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec)) + (size_t)wave * 64 * Cs;
-
-    float cv0 = 0.f, cv1 = 0.f, cv2 = 0.f, cv3 = 0.f;  // per-class cost, C <= 4
-    float ce_max = 0.f, ce_den = 1.f;                   // softmax pieces, C > 4
-
-    if (!TILE) {
-        const float *lg = set.logits + row * (size_t)C;
-        float x[4];
+    // cost_class * class cost of every class, once per query
+    float wc[QPT][C];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) x[c] = (c < C) ? lg[c] : 0.0f;
+    for (int i = 0; i < QPT; ++i) {
         if (prm.cls_mode == 0) {
-            float mx = x[0];
+            float mx = x[i][0];
 #pragma unroll
-            for (int c = 1; c < 4; ++c) if (c < C) mx = fmaxf(mx, x[c]);
-            float e[4], den = 0.0f;
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[i][c]);
+            float e[C], den = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { e[c] = (c < C) ? expf(x[c] - mx) : 0.0f; if (c < C) den += e[c]; }
-            cv0 = -(e[0] / den); cv1 = -(e[1] / den); cv2 = -(e[2] / den); cv3 = -(e[3] / den);
+            for (int c = 0; c < C; ++c) { e[c] = expf(x[i][c] - mx); den += e[c]; }
+#pragma unroll
+            for (int c = 0; c < C; ++c) wc[i][c] = prm.w_class * (-(e[c] / den));
         } else {
-            cv0 = focal_cost(x[0], prm.focal_alpha, prm.focal_gamma);
-            if (C > 1) cv1 = focal_cost(x[1], prm.focal_alpha, prm.focal_gamma);
-            if (C > 2) cv2 = focal_cost(x[2], prm.focal_alpha, prm.focal_gamma);
-            if (C > 3) cv3 = focal_cost(x[3], prm.focal_alpha, prm.focal_gamma);
-        }
-    } else {
-        // stream this wave's 64 logit rows (contiguous in memory) into its LDS tile
-        const int qw0 = q0 + wave * 64;
-        const int nq = min(64, Q - qw0);
-        if (nq > 0) {
-            const float *src = set.logits + ((size_t)b * Q + qw0) * (size_t)C;
-            const int n = nq * C;
-            const int step_r = 256 / C, step_c = 256 % C;
-            int e0 = lane * 4;
-            int r = e0 / C, c = e0 - r * C;
-            const bool vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-            constexpr int U = 8;   // 16-byte loads kept in flight per lane
-            for (int base = 0; base < n; base += 256 * U) {
-                float4 v[U];
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int e = base + k * 256 + lane * 4;
-                    if (vec_ok && e + 3 < n) {
-                        v[k] = *reinterpret_cast<const float4 *>(src + e);
-                    } else {
-                        v[k].x = (e < n) ? src[e] : 0.f;
-                        v[k].y = (e + 1 < n) ? src[e + 1] : 0.f;
-                        v[k].z = (e + 2 < n) ? src[e + 2] : 0.f;
-                        v[k].w = (e + 3 < n) ? src[e + 3] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int e = base + k * 256 + lane * 4;
-                    const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-                    int rr = r, cc = c;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (e + i < n) wt[rr * Cs + cc] = vv[i];
-                        if (++cc == C) { cc = 0; ++rr; }
-                    }
-                    c += step_c; r += step_r;
-                    if (c >= C) { c -= C; ++r; }
-                }
-            }
-        }
-        __syncthreads();
-        if (prm.cls_mode == 0) {
-            const float *xr = wt + lane * Cs;
-            float mx = xr[0];
-            for (int c = 1; c < C; ++c) mx = fmaxf(mx, xr[c]);
-            float den = 0.0f;
-            for (int c = 0; c < C; ++c) den += expf(xr[c] - mx);
-            ce_max = mx; ce_den = den;
+            for (int c = 0; c < C; ++c) wc[i][c] = prm.w_class * focal_cost(x[i][c], prm.focal_alpha, prm.focal_gamma);
         }
     }
 
-    float *out = cost + set.cost_off + (size_t)t0 * set.q_stride + q;
+    const int qs = set.q_stride;
+    float *out = cost + set.cost_off + (size_t)t0 * qs + q0;
+    // a QPT-wide store needs all its queries in range and natural alignment of the row start
+    const bool wide = (q0 + QPT <= Q) && (qs % QPT == 0) && ((reinterpret_cast<uintptr_t>(out) & (4 * QPT - 1)) == 0);
 
     for (int tc = 0; tc < T; tc += TCHUNK) {
         const int nt = min(TCHUNK, T - tc);
-        if (tc > 0) __syncthreads();
-        for (int i = threadIdx.x; i < nt; i += blockDim.x) {
-            const int t = t0 + tc + i;
-            const float4 gb = reinterpret_cast<const float4 *>(tboxes)[t];
-            long long l = labels[t];
-            TgtRec g;
-            g.cx = gb.x; g.cy = gb.y; g.w = gb.z; g.h = gb.w;
-            g.x0 = g.cx - 0.5f * g.w; g.y0 = g.cy - 0.5f * g.h;
-            g.x1 = g.cx + 0.5f * g.w; g.y1 = g.cy + 0.5f * g.h;
-            g.area = (g.x1 - g.x0) * (g.y1 - g.y0);
-            if (!((g.x1 >= g.x0) && (g.y1 >= g.y0))) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
-            if (l < -(long long)C || l >= (long long)C) { dm::raise_status(status, DM_ST_LABEL_RANGE); l = 0; }
-            if (l < 0) l += C;   // python-style negative index
-            g.label = (int)l; g.pad0 = 0; g.pad1 = 0;
-            tg[i] = g;
+        if (tc > 0) {
+            __syncthreads();
+            stage_targets(tg, labels, tboxes, t0 + tc, nt, C, status);
         }
         __syncthreads();
-        if (active) {
-#pragma unroll 4
+        if (q0 < Q) {
+            TgtRec g = tg[0];
             for (int i = 0; i < nt; ++i) {
-                const TgtRec g = tg[i];
-                float cls;
-                if (!TILE) {
-                    cls = g.label == 0 ? cv0 : (g.label == 1 ? cv1 : (g.label == 2 ? cv2 : cv3));
-                } else {
-                    const float x = wt[lane * Cs + g.label];
-                    cls = prm.cls_mode == 0 ? -(expf(x - ce_max) / ce_den)
-                                            : focal_cost(x, prm.focal_alpha, prm.focal_gamma);
+                const TgtRec gn = tg[min(i + 1, nt - 1)];     // next record in flight while this one is used
+                // select by data, not by branch (the label is wave-uniform and the compiler would
+                // otherwise turn the selects into a scalar branch tree)
+                int l = g.label;
+                asm("" : "+v"(l));
+                vecq r;
+#pragma unroll
+                for (int k = 0; k < QPT; ++k) {
+                    float wcls = wc[k][0];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) wcls = (l == c) ? wc[k][c] : wcls;
+                    r[k] = pair_cost(p[k], g, wcls, prm.w_bbox, prm.w_giou);
                 }
-                out[(size_t)(tc + i) * set.q_stride] = pair_cost(p, g, cls, prm);
+                float *dst = out + (size_t)(tc + i) * qs;
+                if (QPT == 1 || wide) {
+                    *reinterpret_cast<vecq *>(dst) = r;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < QPT; ++k) if (q0 + k < Q) dst[k] = r[k];
+                }
+                g = gn;
+            }
+        }
+    }
+}
+
+// C > 4.  blockDim = 256: wavefront w of the workgroup handles targets t = w (mod 4) of the
+// 64 queries [64 * blockIdx.x, +64); all four stream the 64 x C logit tile into LDS together.
+__global__ __launch_bounds__(256) void cost_tile_kernel(const DmSetArray sets, const int C,
+                                                        const int64_t *__restrict__ labels,
+                                                        const float *__restrict__ tboxes,
+                                                        const int32_t *__restrict__ tgt_off, const DmParams prm,
+                                                        float *__restrict__ cost, int32_t *status)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    TgtRec *tg = reinterpret_cast<TgtRec *>(smem);                                   // [TCHUNK]
+    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [4][64] softmax partials
+    float *tile = part + 256;                                                        // [64][Cs]
+
+    const DmSet &set = sets.s[blockIdx.z];
+    const int b = blockIdx.y;
+    const int Q = set.Q;
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= Q) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = q0 + lane;
+    const bool active = q < Q;
+    const int nq = min(64, Q - q0);
+    const int t0 = tgt_off[b];
+    const int T = tgt_off[b + 1] - t0;
+    const size_t row = (size_t)b * Q + (active ? q : Q - 1);
+    const int Cs = C | 1;                      // odd LDS row stride
+
+    const float4 raw = reinterpret_cast<const float4 *>(set.boxes)[row];
+    if (T > 0) {
+        // stream the tile: rows q0 .. q0+nq-1 are contiguous in memory; lane-consecutive dwords
+        // land on consecutive LDS banks
+        const float *src = set.logits + ((size_t)b * Q + q0) * (size_t)C;
+        const int n = nq * C;
+        const int step_r = 256 / C, step_c = 256 % C;
+        int r = tid / C, c = tid - r * C;
+        constexpr int U = 8;
+        for (int base = 0; base < n; base += 256 * U) {
+            float v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = base + k * 256 + tid;
+                v[k] = src[min(e, n - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = base + k * 256 + tid;
+                if (e < n) tile[r * Cs + c] = v[k];
+                c += step_c; r += step_r;
+                if (c >= C) { c -= C; ++r; }
+            }
+        }
+        stage_targets(tg, labels, tboxes, t0, min(TCHUNK, T), C, status);
+    }
+    const PredBox p = make_pred(raw);
+    if (active && wave == 0 && !pred_valid(p)) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+    if (T == 0) return;
+    __syncthreads();
+
+    const float *xr = tile + lane * Cs;
+    float ce_max = 0.0f, ce_den = 1.0f;
+    if (prm.cls_mode == 0) {
+        // softmax statistics of the lane's row, the class range split over the four wavefronts
+        float mx = -__builtin_huge_valf();
+        for (int c = wave; c < C; c += 4) mx = fmaxf(mx, xr[c]);
+        part[wave * 64 + lane] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(part[lane], part[64 + lane]), fmaxf(part[128 + lane], part[192 + lane]));
+        __syncthreads();
+        float den = 0.0f;
+        for (int c = wave; c < C; c += 4) den += expf(xr[c] - mx);
+        part[wave * 64 + lane] = den;
+        __syncthreads();
+        ce_max = mx;
+        ce_den = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+    }
+
+    const int qs = set.q_stride;
+    float *out = cost + set.cost_off + (size_t)t0 * qs + q;
+
+    for (int tc = 0; tc < T; tc += TCHUNK) {
+        const int nt = min(TCHUNK, T - tc);
+        if (tc > 0) {
+            __syncthreads();
+            stage_targets(tg, labels, tboxes, t0 + tc, nt, C, status);
+            __syncthreads();
+        }
+        if (active) {
+            for (int i = wave; i < nt; i += 4) {
+                const TgtRec g = tg[i];
+                const float xl = xr[g.label];
+                const float cls = prm.cls_mode == 0 ? -(expf(xl - ce_max) / ce_den)
+                                                    : focal_cost(xl, prm.focal_alpha, prm.focal_gamma);
+                out[(size_t)(tc + i) * qs] = pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
             }
         }
     }
@@ -227,10 +343,15 @@ int pick_waves(int Q, int max_waves)
 }
 
 thread_local char g_hip_err[256] = "";
+int g_cost_qpt = 0;   // 0: automatic; 1 / 2: force the queries-per-thread variant (testing aid)
 
 }  // namespace
 
 extern "C" const char *dm_last_hip_error(void) { return g_hip_err; }
+
+// Testing aid: 0 restores the automatic choice, 1 / 2 force one / two queries per thread in
+// the small-C cost kernel.
+extern "C" void dm_debug_cost_queries_per_thread(int qpt) { g_cost_qpt = (qpt == 1 || qpt == 2) ? qpt : 0; }
 
 namespace dm {
 int check_hip(hipError_t e, const char *what)
@@ -248,54 +369,64 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     if (S < 0 || B < 0 || C < 1 || max_T < 0 || !params || !status) return DM_E_INVALID_ARG;
     if (S == 0 || B == 0) return DM_OK;
     if (!sets || !tgt_off || (max_T > 0 && (!tgt_labels || !tgt_boxes || !cost))) return DM_E_INVALID_ARG;
-    if (B > 65535) return DM_E_UNSUPPORTED;
+    if (B > 65535 || S > 4096) return DM_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tile = C > 4;
-    const int Cs = C | 1;
-    const size_t tile_wave_bytes = tile ? (size_t)64 * Cs * sizeof(float) : 0;
-    if (tile_wave_bytes + TCHUNK * sizeof(TgtRec) > 160 * 1024) return DM_E_UNSUPPORTED;
-    int max_waves = 8;
-    if (tile) {
-        max_waves = (int)((48 * 1024) / tile_wave_bytes);
-        if (max_waves < 1) max_waves = 1;
-        if (max_waves > 4) max_waves = 4;
+    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + 256 * sizeof(float) + (size_t)64 * (C | 1) * sizeof(float);
+    if (tile && tile_lds > 160 * 1024) return DM_E_UNSUPPORTED;
+    if (tile && tile_lds > 64 * 1024) {
+        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_tile_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds),
+                               "hipFuncSetAttribute(cost_tile_kernel)");
+        if (rc != DM_OK) return rc;
     }
 
     // one launch per group of sets with equal Q (the tile decomposition depends on Q)
     bool done[4096] = {false};
-    if (S > 4096) return DM_E_UNSUPPORTED;
     for (int s0 = 0; s0 < S; ++s0) {
         if (done[s0]) continue;
         const int Q = sets[s0].Q;
-        if (Q < 1 || sets[s0].q_stride < Q || !sets[s0].logits || !sets[s0].boxes) return DM_E_INVALID_ARG;
         DmSetArray arr;
         int n = 0;
         for (int s = s0; s <= S; ++s) {
-            const bool take = s < S && !done[s] && sets[s].Q == Q;
-            if (take) {
-                if (sets[s].q_stride < Q || !sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
+            if (s < S && !done[s] && sets[s].Q == Q) {
+                if (Q < 1 || sets[s].q_stride < Q || !sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
                 arr.s[n++] = sets[s];
                 done[s] = true;
             }
             if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
-                const int waves = pick_waves(Q, max_waves);
-                const int threads = waves * 64;
-                const size_t lds = TCHUNK * sizeof(TgtRec) + tile_wave_bytes * waves;
-                dim3 grid((Q + threads - 1) / threads, B, n);
                 if (tile) {
-                    if (lds > 64 * 1024) {
-                        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_kernel<true>),
-                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                                               "hipFuncSetAttribute(cost_kernel)");
-                        if (rc != DM_OK) return rc;
-                    }
-                    hipLaunchKernelGGL(cost_kernel<true>, grid, dim3(threads), lds, st, arr, C, tgt_labels,
-                                       tgt_boxes, tgt_off, *params, cost, status);
+                    dim3 grid((Q + 63) / 64, B, n);
+                    hipLaunchKernelGGL(cost_tile_kernel, grid, dim3(256), tile_lds, st, arr, C, tgt_labels, tgt_boxes,
+                                       tgt_off, *params, cost, status);
                 } else {
-                    hipLaunchKernelGGL(cost_kernel<false>, grid, dim3(threads), lds, st, arr, C, tgt_labels,
-                                       tgt_boxes, tgt_off, *params, cost, status);
+                    // one query per thread keeps the most wavefronts in flight; the two-query
+                    // variant (8-byte stores) measured no faster at any size and stays a testing aid
+                    const int qpt = g_cost_qpt ? g_cost_qpt : 1;
+                    const int lanes = (Q + qpt - 1) / qpt;
+                    const int threads = 64 * pick_waves(lanes, 8);
+                    dim3 grid((lanes + threads - 1) / threads, B, n);
+#define DM_LAUNCH_SMALL(CC, QQ)                                                                                  \
+    hipLaunchKernelGGL((cost_small_kernel<CC, QQ>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, \
+                       *params, cost, status)
+                    if (qpt == 1) {
+                        switch (C) {
+                        case 1: DM_LAUNCH_SMALL(1, 1); break;
+                        case 2: DM_LAUNCH_SMALL(2, 1); break;
+                        case 3: DM_LAUNCH_SMALL(3, 1); break;
+                        default: DM_LAUNCH_SMALL(4, 1); break;
+                        }
+                    } else {
+                        switch (C) {
+                        case 1: DM_LAUNCH_SMALL(1, 2); break;
+                        case 2: DM_LAUNCH_SMALL(2, 2); break;
+                        case 3: DM_LAUNCH_SMALL(3, 2); break;
+                        default: DM_LAUNCH_SMALL(4, 2); break;
+                        }
+                    }
+#undef DM_LAUNCH_SMALL
                 }
-                int rc = dm::check_hip(hipGetLastError(), "cost_kernel launch");
+                int rc = dm::check_hip(hipGetLastError(), "cost kernel launch");
                 if (rc != DM_OK) return rc;
                 n = 0;
             }

@@ -27,8 +27,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--which", default="cost,lap")
+    ap.add_argument("--qpt", type=int, default=0)
+    ap.add_argument("--lapmode", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
+    lib.dm_debug_cost_queries_per_thread(args.qpt)
+    lib.dm_debug_force_generic_lap(args.lapmode)
     wl, sets, targets = synth.make_workload(args.workload, device=dev, batch=args.batch)
     packed = PackedTargets(targets, dev)
     S, B, M = len(sets), packed.batch, packed.total
