@@ -24,6 +24,8 @@ from ._lib import DmParams, DmSet, lib
 
 Indices = List[Tuple[torch.Tensor, torch.Tensor]]
 
+_split_with_sizes = torch.ops.aten.unsafe_split_with_sizes.default
+
 
 class PackedTargets:
     """The targets of one batch, packed once and shared by every output set of the step.
@@ -173,8 +175,7 @@ class HungarianMatcher(torch.nn.Module):
 
         cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
         # [src (S*M) | tgt (S*M) | status word]
-        out = torch.empty(2 * S * M + 1, dtype=torch.int64, device=device)
-        out[-1:].zero_()
+        out = torch.zeros(2 * S * M + 1, dtype=torch.int64, device=device)
         status_ptr = out.data_ptr() + 8 * 2 * S * M
         params = self._params()
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -184,42 +185,42 @@ class HungarianMatcher(torch.nn.Module):
                                   cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M, status_ptr, stream)
         _lib.check(rc, "dm_match_f32")
 
-        pair_counts = [[min(q, t) for t in sizes] for q in queries]
         if device_indices:
             self.last_status = out[-1:]
-            flat = out
+            result = self._split(out, S, M, sizes, queries, packed.offsets_host)
         else:
             host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
             host.copy_(out, non_blocking=True)
+            # the per-image views depend on shapes only: build them while the GPU is working
+            result = self._split(host, S, M, sizes, queries, packed.offsets_host)
             torch.cuda.current_stream(device).synchronize()
-            _raise_for_status(int(host[-1].item()) & 0xFFFFFFFF)
-            flat = host
-
-        result = self._split(flat, S, M, sizes, queries, pair_counts, packed.offsets_host)
+            _raise_for_status(int(host[-1]) & 0xFFFFFFFF)
         if return_cost:
             costs = [cost[o:o + M * st].view(M, st)[:, :q] for (o, st), q in zip(strides, queries)]
             return result, costs
         return result
 
     @staticmethod
-    def _split(flat, S, M, sizes, queries, pair_counts, offsets):
-        src_all, tgt_all = flat[:S * M], flat[S * M:2 * S * M]
+    def _split(flat, S, M, sizes, queries, offsets):
+        """Views of the flat [src | tgt | status] buffer as list (sets) of lists (images) of tuples."""
         if M == 0:
             empty = flat[:0]
             return [[(empty, empty) for _ in sizes] for _ in range(S)]
-        result = []
+        src_all, tgt_all = flat[:S * M], flat[S * M:2 * S * M]
+        B = len(sizes)
         if min(queries) >= max(sizes):
-            # every image's region is completely filled: one split call for everything
-            src_parts = src_all.split(sizes * S)
-            tgt_parts = tgt_all.split(sizes * S)
-            B = len(sizes)
-            for s in range(S):
-                result.append(list(zip(src_parts[s * B:(s + 1) * B], tgt_parts[s * B:(s + 1) * B])))
-            return result
-        for s in range(S):
+            # every image's region is completely filled: one split call per side for everything
+            # (index tensors carry no gradient, so the untracked split is safe and cheaper)
+            src_parts = _split_with_sizes(src_all, sizes * S)
+            tgt_parts = _split_with_sizes(tgt_all, sizes * S)
+            pairs = list(zip(src_parts, tgt_parts))
+            return [pairs[s * B:(s + 1) * B] for s in range(S)]
+        result = []
+        for s, q in enumerate(queries):
             per_image = []
-            for b, n in enumerate(pair_counts[s]):
+            for b, t in enumerate(sizes):
                 lo = s * M + int(offsets[b])
+                n = min(q, t)
                 per_image.append((src_all[lo:lo + n], tgt_all[lo:lo + n]))
             result.append(per_image)
         return result

@@ -1,0 +1,78 @@
+"""CPU checks of the C-ABI library: it loads without a GPU and exports every symbol that
+include/detr_match.h declares.  No compute entry point is called here."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "detr_match.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_entry_points():
+    names = declared_functions()
+    for required in ("dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_abi_version", "dm_strerror"):
+        assert required in names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import detr_amd
+
+    lib = ctypes.CDLL(detr_amd.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert sorted(detr_amd._lib.EXPORTS) == declared_functions()
+
+
+def test_abi_version_and_strerror():
+    import detr_amd
+
+    assert detr_amd.lib.dm_abi_version() == 1
+    assert detr_amd.lib.dm_strerror(0) == b"ok"
+    assert b"invalid" in detr_amd.lib.dm_strerror(-1)
+    assert detr_amd.lib.dm_device_count() >= 0
+
+
+def test_struct_layouts_match_the_header():
+    from detr_amd._lib import DmParams, DmSet
+
+    assert ctypes.sizeof(DmSet) == 40      # 2 pointers, 2 int64, 2 int32
+    assert DmSet.cost_off.offset == 16 and DmSet.Q.offset == 32 and DmSet.q_stride.offset == 36
+    assert ctypes.sizeof(DmParams) == 24
+
+
+def test_argument_validation_without_gpu():
+    """Argument errors are reported before any HIP call is made."""
+    import detr_amd
+    from detr_amd._lib import DmParams, DmSet
+
+    lib = detr_amd.lib
+    sets = (DmSet * 1)()
+    prm = DmParams(0, 1.0, 1.0, 1.0, 0.25, 2.0)
+    # negative sizes / missing status pointer
+    assert lib.dm_cost_f32(sets, -1, 1, 3, None, None, None, 0, ctypes.byref(prm), None, None, None) == -1
+    assert lib.dm_lap_f32(sets, 1, 1, None, None, None, 4, None, None, None, None) == -1
+    # nothing to do: succeeds without touching the device
+    status = (ctypes.c_int32 * 1)(0)
+    assert lib.dm_cost_f32(sets, 0, 0, 3, None, None, None, 0, ctypes.byref(prm), None, status, None) == 0
+    assert lib.dm_lap_f32(sets, 1, 4, None, None, None, 0, None, None, status, None) == 0
+
+
+def test_matcher_refuses_cpu_tensors():
+    import pytest
+    import torch
+
+    import detr_amd
+
+    m = detr_amd.HungarianMatcher("ce", 1.0, 1.0, 1.0)
+    out = {"pred_logits": torch.zeros(1, 4, 3), "pred_boxes": torch.full((1, 4, 4), 0.5)}
+    tg = [{"labels": torch.zeros(2, dtype=torch.int64), "boxes": torch.full((2, 4), 0.5)}]
+    with pytest.raises(RuntimeError):
+        m(out, tg)
+    with pytest.raises(AssertionError):
+        detr_amd.HungarianMatcher("ce", 0, 0, 0)

@@ -1,0 +1,117 @@
+"""CPU tests of the host-side logic: result splitting, status mapping, synthetic workloads,
+and the data-parallel helpers (world_size 2 over gloo)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import detr_amd
+from detr_amd import synth
+from detr_amd.dist import all_reduce_num_boxes, matched_box_counts, shard_range
+from detr_amd.matcher import HungarianMatcher, _raise_for_status
+
+
+def test_split_regular_and_ragged():
+    sizes, queries = [3, 0, 2], [5, 4]
+    S, M = 2, 5
+    flat = torch.arange(2 * S * M + 1, dtype=torch.int64)
+    off = np.array([0, 3, 3, 5])
+    res = HungarianMatcher._split(flat, S, M, sizes, queries, off)
+    assert [len(r) for r in res] == [3, 3]
+    assert res[0][0][0].tolist() == [0, 1, 2] and res[0][0][1].tolist() == [10, 11, 12]
+    assert res[0][1][0].numel() == 0
+    assert res[1][2][0].tolist() == [8, 9] and res[1][2][1].tolist() == [18, 19]
+    # more targets than queries: only min(Q, T) pairs per image
+    res = HungarianMatcher._split(flat, S, M, sizes, [2, 1], off)
+    assert res[0][0][0].tolist() == [0, 1] and res[1][0][0].tolist() == [5]
+    assert res[1][2][1].tolist() == [18]
+    # no targets at all
+    res = HungarianMatcher._split(torch.zeros(1, dtype=torch.int64), 2, 0, [0, 0], [5, 4], np.array([0, 0, 0]))
+    assert all(a.numel() == 0 and b.numel() == 0 for r in res for a, b in r)
+
+
+def test_status_precedence_matches_reference_call_order():
+    from detr_amd import _lib
+
+    with pytest.raises(IndexError):
+        _raise_for_status(_lib.ST_LABEL_RANGE | _lib.ST_DEGENERATE_BOX | _lib.ST_INVALID_COST)
+    with pytest.raises(AssertionError):
+        _raise_for_status(_lib.ST_DEGENERATE_BOX | _lib.ST_INVALID_COST)
+    with pytest.raises(ValueError):
+        _raise_for_status(_lib.ST_INVALID_COST)
+    with pytest.raises(ValueError):
+        _raise_for_status(_lib.ST_INFEASIBLE)
+    _raise_for_status(0)
+
+
+def test_synthetic_workloads_are_deterministic_and_valid():
+    for name in ("cfg1", "cfg2", "cfg3", "cfg3_hw"):
+        wl, sets, targets = synth.make_workload(name, batch=4)
+        wl2, sets2, targets2 = synth.make_workload(name, batch=4)
+        assert len(sets) == len(wl.set_queries)
+        for a, b in zip(sets, sets2):
+            assert torch.equal(a["pred_logits"], b["pred_logits"]) and torch.equal(a["pred_boxes"], b["pred_boxes"])
+        for s, q in zip(sets, wl.set_queries):
+            assert s["pred_logits"].shape == (4, q, wl.n_logits) and s["pred_boxes"].shape == (4, q, 4)
+            bx = s["pred_boxes"]
+            assert (bx[..., 2:] > 0).all() and (bx >= 0).all()
+        for t in targets:
+            assert t["labels"].dtype == torch.int64 and t["boxes"].shape == (len(t["labels"]), 4)
+            assert (t["labels"] >= 0).all() and (t["labels"] < wl.n_label_classes).all()
+    a = synth.make_workload("cfg2", batch=4, rank=0)[1][0]["pred_logits"]
+    b = synth.make_workload("cfg2", batch=4, rank=1)[1][0]["pred_logits"]
+    assert not torch.equal(a, b)
+    counts = synth.target_counts("heavy_tail", 2000, np.random.default_rng(0))
+    assert counts.min() >= 0 and counts.max() <= 100 and counts.mean() > 10
+
+
+def test_matched_box_counts_and_shards():
+    assert matched_box_counts([3, 0, 9], [5, 2]) == [3 + 0 + 5, 2 + 0 + 2]
+    covered = []
+    for r in range(4):
+        lo, hi = shard_range(10, r, 4)
+        covered += list(range(lo, hi))
+    assert covered == list(range(10))
+    assert shard_range(8, 1, 2) == (4, 8)
+    # no process group: local counts, clamped
+    out = all_reduce_num_boxes([0, 7], "cpu")
+    assert out.tolist() == [1.0, 7.0]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank owns a shard of the images; the matched-box counts are summed in ONE collective
+        _, _, targets = synth.make_workload("cfg2", batch=8)
+        lo, hi = shard_range(8, rank, world)
+        sizes = [len(t["labels"]) for t in targets[lo:hi]]
+        counts = matched_box_counts(sizes, [600] * 6 + [10])
+        out = all_reduce_num_boxes(counts, "cpu")
+        results[rank] = out.tolist()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_num_boxes_all_reduce_world_size_2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_dp_worker, args=(world, port, results), nprocs=world, join=True)
+        got = [results[r] for r in range(world)]
+    _, _, targets = synth.make_workload("cfg2", batch=8)
+    sizes = [len(t["labels"]) for t in targets]
+    expect = [max(c / world, 1.0) for c in matched_box_counts(sizes, [600] * 6 + [10])]
+    assert got[0] == got[1]
+    np.testing.assert_allclose(got[0], expect, rtol=1e-6)
