@@ -265,22 +265,36 @@ __global__ __launch_bounds__(256) void cost_tile_kernel(const DmSetArray sets, c
         // land on consecutive LDS banks
         const float *src = set.logits + ((size_t)b * Q + q0) * (size_t)C;
         const int n = nq * C;
-        const int step_r = 256 / C, step_c = 256 % C;
-        int r = tid / C, c = tid - r * C;
-        constexpr int U = 8;
-        for (int base = 0; base < n; base += 256 * U) {
-            float v[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const int e = base + k * 256 + tid;
-                v[k] = src[min(e, n - 1)];
+        if ((C & 1) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            // odd C: the LDS image (row stride C) is a linear copy of the rows -> LDS-DMA, 1 KB per
+            // wave instruction, no registers, every piece in flight at once
+            for (int base = wave * 256; base < n; base += 4 * 256) {
+                const int e = base + lane * 4;
+                if (e + 3 < n)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e),
+                                                     (__attribute__((address_space(3))) void *)(tile + base), 16, 0, 0);
             }
+            const int n4 = n & ~3;
+            if (tid < n - n4) tile[n4 + tid] = src[n4 + tid];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int step_r = 256 / C, step_c = 256 % C;
+            int r = tid / C, c = tid - r * C;
+            constexpr int U = 8;
+            for (int base = 0; base < n; base += 256 * U) {
+                float v[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const int e = base + k * 256 + tid;
-                if (e < n) tile[r * Cs + c] = v[k];
-                c += step_c; r += step_r;
-                if (c >= C) { c -= C; ++r; }
+                for (int k = 0; k < U; ++k) {
+                    const int e = base + k * 256 + tid;
+                    v[k] = src[min(e, n - 1)];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int e = base + k * 256 + tid;
+                    if (e < n) tile[r * Cs + c] = v[k];
+                    c += step_c; r += step_r;
+                    if (c >= C) { c -= C; ++r; }
+                }
             }
         }
         stage_targets(tg, labels, tboxes, t0, min(TCHUNK, T), C, status);
