@@ -59,12 +59,22 @@ __device__ __forceinline__ float pow_gamma(float x, float gamma)
     return powf(x, gamma);
 }
 
-// matcher.py:76-81 for one logit
+// matcher.py:76-81 for one logit.
+// sigmoid and its complement are formed from a = exp(-|x|) as 1/(1+a) and a/(1+a): the
+// complement keeps full relative accuracy where the reference's fp32 `1 - p` has lost it
+// (it stays within one rounding of p of the reference's value); exp and log are the
+// hardware v_exp_f32 / v_log_f32 (1 ulp).
 __device__ __forceinline__ float focal_cost(float x, float alpha, float gamma)
 {
-    const float p = 1.0f / (1.0f + expf(-x));
-    const float neg = ((1.0f - alpha) * pow_gamma(p, gamma)) * (-logf((1.0f - p) + 1e-8f));
-    const float pos = (alpha * pow_gamma(1.0f - p, gamma)) * (-logf(p + 1e-8f));
+    const float a = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896f);
+    const float big = __builtin_amdgcn_rcpf(1.0f + a);     // sigmoid(|x|)
+    const float small = a * big;                            // sigmoid(-|x|)
+    const float p = x >= 0.0f ? big : small;
+    const float q = x >= 0.0f ? small : big;                // 1 - p
+    const float nlog_q = -(__builtin_amdgcn_logf(q + 1e-8f) * 0.693147180559945f);
+    const float nlog_p = -(__builtin_amdgcn_logf(p + 1e-8f) * 0.693147180559945f);
+    const float neg = ((1.0f - alpha) * pow_gamma(p, gamma)) * nlog_q;
+    const float pos = (alpha * pow_gamma(q, gamma)) * nlog_p;
     return pos - neg;
 }
 
