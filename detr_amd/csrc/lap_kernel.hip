@@ -136,7 +136,10 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 
     const int qs = set.q_stride;
     const float *cg = cost + set.cost_off + (size_t)t0 * qs;
-    const int R = min(nr, lds_cost_floats / nc);            // rows resident in LDS
+    // rows resident in LDS keep the global row stride when they can be copied linearly
+    const bool linear = (qs & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0;
+    const int ls = linear ? qs : nc;                        // LDS row stride
+    const int R = min(nr, lds_cost_floats / ls);            // rows resident in LDS
 
     double v[NCOL], spc[NCOL], v_real[NCOL], spc_real[NCOL];
     int r4c[NCOL], pth[NCOL], jc[NCOL];
@@ -157,9 +160,9 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 
     // Stage the first R rows in LDS.  A dense, 16-byte aligned block goes through LDS-DMA
     // (no registers, every piece in flight at once); anything else through registers.
-    const int nfl = R * nc;
+    const int nfl = R * ls;
     bool bad = false;
-    if (qs == nc && (nc & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0) {
+    if (linear) {
         for (int base = 0; base < nfl; base += 256) {
             const int e = base + lane * 4;
             if (e < nfl)
@@ -168,10 +171,12 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int e = lane * 4; e < nfl; e += 256) {
-            const float4 x = *reinterpret_cast<const float4 *>(crow + e);
-            bad |= cost_is_invalid(x.x) | cost_is_invalid(x.y) | cost_is_invalid(x.z) | cost_is_invalid(x.w);
-        }
+        for (int i = 0; i < R; ++i)      // (the padding behind column nc is never written: skip it)
+            for (int e = lane * 4; e < nc; e += 256) {
+                const float4 x = *reinterpret_cast<const float4 *>(crow + i * ls + e);
+                bad |= cost_is_invalid(x.x) | (e + 1 < nc && cost_is_invalid(x.y)) |
+                       (e + 2 < nc && cost_is_invalid(x.z)) | (e + 3 < nc && cost_is_invalid(x.w));
+            }
     } else {
         for (int i = 0; i < R; ++i) {
             float c[NCOL];
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 bad |= cost_is_invalid(c[k]);
-                crow[i * nc + jc[k]] = c[k];
+                crow[i * ls + jc[k]] = c[k];
             }
         }
     }
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
             const int jl = __builtin_amdgcn_readfirstlane(remaining[n - 1]);   // column at the last list position
             float c[NCOL];
             if (i < R) {
-                const float *row = crow + i * nc;
+                const float *row = crow + i * ls;
 #pragma unroll
                 for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
             } else {
@@ -437,7 +442,10 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
 
     const int qs = set.q_stride;
     const float *cg = cost + set.cost_off + (size_t)t0 * qs;
-    const int R = min(nr, lds_cost_floats / nc);            // rows resident in LDS
+    // rows resident in LDS keep the global row stride when they can be copied linearly
+    const bool linear = (qs & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0;
+    const int ls = linear ? qs : nc;                        // LDS row stride
+    const int R = min(nr, lds_cost_floats / ls);            // rows resident in LDS
 
     double v[NCOL], spc[NCOL];
     int r4c[NCOL], pth[NCOL], jc[NCOL], posr[NCOL];
@@ -458,9 +466,9 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
 
     // Stage the first R rows in LDS.  A dense, 16-byte aligned block goes through LDS-DMA
     // (no registers, every piece in flight at once); anything else through registers.
-    const int nfl = R * nc;
+    const int nfl = R * ls;
     bool bad = false;
-    if (qs == nc && (nc & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0) {
+    if (linear) {
         for (int base = wave * 256; base < nfl; base += W * 256) {
             const int e = base + lane * 4;
             if (e < nfl)
@@ -469,10 +477,12 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int e = tid * 4; e < nfl; e += BS * 4) {
-            const float4 x = *reinterpret_cast<const float4 *>(crow + e);
-            bad |= cost_is_invalid(x.x) | cost_is_invalid(x.y) | cost_is_invalid(x.z) | cost_is_invalid(x.w);
-        }
+        for (int i = 0; i < R; ++i)      // (the padding behind column nc is never written: skip it)
+            for (int e = tid * 4; e < nc; e += BS * 4) {
+                const float4 x = *reinterpret_cast<const float4 *>(crow + i * ls + e);
+                bad |= cost_is_invalid(x.x) | (e + 1 < nc && cost_is_invalid(x.y)) |
+                       (e + 2 < nc && cost_is_invalid(x.z)) | (e + 3 < nc && cost_is_invalid(x.w));
+            }
     } else {
         for (int i = 0; i < R; ++i) {
             float c[NCOL];
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 bad |= cost_is_invalid(c[k]);
-                crow[i * nc + jc[k]] = c[k];
+                crow[i * ls + jc[k]] = c[k];
             }
         }
     }
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
             const unsigned live = valid & ~sc;
             float c[NCOL];
             if (in_lds) {
-                const float *row = crow + i * nc;
+                const float *row = crow + i * ls;
 #pragma unroll
                 for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
             } else {
@@ -758,13 +768,13 @@ int ncol_class(int Q)
 
 template <int NCOL>
 int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
+                const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out,
                 int32_t *status, hipStream_t st)
 {
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const size_t fixed = (size_t)t_cap * (8 + 4 + 4) + (size_t)4 * 64 * NCOL * 4;
-    size_t want = (size_t)fast_T * max_Q * sizeof(float);
+    size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS; many: keep more resident
     const size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : 40 * 1024;
     if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
@@ -784,10 +794,10 @@ int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const in
 }
 
 int launch_wave_dyn(int ncol, const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                    const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
+                    const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out,
                     int32_t *status, hipStream_t st)
 {
-#define DM_CASE(N) case N: return launch_wave<N>(arr, n, B, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st)
+#define DM_CASE(N) case N: return launch_wave<N>(arr, n, B, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, status, st)
     switch (ncol) {
         DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
         DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
@@ -815,14 +825,14 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
 
 template <int NCOL>
 int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *cost, const int32_t *tgt_off,
-                 const int32_t *order, int max_T, int max_Q, int64_t *src_out, int64_t *tgt_out,
+                 const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out,
                  int32_t *status, hipStream_t st)
 {
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const int qcap = 64 * waves * NCOL;
     const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * (8 + 4 + 4 + 4) + (size_t)3 * qcap * 4;
-    size_t want = (size_t)fast_T * max_Q * sizeof(float);
+    size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS; many: keep more resident
     const size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : 48 * 1024;
     if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
@@ -842,10 +852,10 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
 }
 
 int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, const float *cost,
-                     const int32_t *tgt_off, const int32_t *order, int max_T, int max_Q, int64_t *src_out,
+                     const int32_t *tgt_off, const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out,
                      int64_t *tgt_out, int32_t *status, hipStream_t st)
 {
-#define DM_CASE(N) case N: return launch_block<N>(arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, src_out, tgt_out, status, st)
+#define DM_CASE(N) case N: return launch_block<N>(arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, status, st)
     switch (ncol) {
         DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
         DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
@@ -892,17 +902,22 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
             const bool use_block = g_lap_mode == 2 || (g_lap_mode == 0 && P * ((Q + 63) / 64) <= 6144 * 4);
             if (use_block) pick_shape(Q, P, &ncol, &waves);
             DmSetArray arr;
-            int n = 0;
+            int n = 0, max_stride = Q;
             for (int s = s0; s <= S; ++s) {
-                if (s < S && !done[s] && sets[s].Q == Q) { arr.s[n++] = sets[s]; done[s] = true; }
+                if (s < S && !done[s] && sets[s].Q == Q) {
+                    arr.s[n++] = sets[s];
+                    done[s] = true;
+                    if (sets[s].q_stride > max_stride) max_stride = sets[s].q_stride;
+                }
                 if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
                     int rc = use_block
-                                 ? launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, src_out,
-                                                    tgt_out, status, st)
-                                 : launch_wave_dyn(ncol, arr, n, B, cost, tgt_off, order, max_T, Q, src_out, tgt_out,
-                                                   status, st);
+                                 ? launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, max_stride,
+                                                    src_out, tgt_out, status, st)
+                                 : launch_wave_dyn(ncol, arr, n, B, cost, tgt_off, order, max_T, Q, max_stride,
+                                                   src_out, tgt_out, status, st);
                     if (rc != DM_OK) return rc;
                     n = 0;
+                    max_stride = Q;
                 }
             }
         }

@@ -40,7 +40,7 @@ def batched_linear_sum_assignment(costs: Sequence[torch.Tensor]) -> List[Tuple[t
             for i in idxs:
                 results[i] = (empty, empty)
             continue
-        stride = (Q + 3) & ~3
+        stride = (Q + 31) & ~31
         block = torch.zeros(M, stride, dtype=torch.float32, device=device)
         # rows are targets: the kernels hold the transpose of scipy's [Q, T] argument
         block[:, :Q] = torch.cat([costs[i].t() for i in idxs if costs[i].shape[1] > 0], dim=0)

@@ -166,7 +166,7 @@ class HungarianMatcher(torch.nn.Module):
         cost_off = 0
         strides = []
         for s, ((logits, boxes), q) in enumerate(zip(keep, queries)):
-            stride = (q + 3) & ~3
+            stride = (q + 31) & ~31
             sets[s].logits, sets[s].boxes = logits.data_ptr(), boxes.data_ptr()
             sets[s].cost_off, sets[s].out_off = cost_off, s * M
             sets[s].Q, sets[s].q_stride = q, stride

@@ -24,7 +24,7 @@ S, B, M = len(sets), packed.batch, packed.total
 arr = (DmSet * S)()
 off = 0
 for s, o in enumerate(sets):
-    q = o["pred_logits"].shape[1]; st = (q + 3) & ~3
+    q = o["pred_logits"].shape[1]; st = (q + 31) & ~31
     arr[s].logits, arr[s].boxes = o["pred_logits"].data_ptr(), o["pred_boxes"].data_ptr()
     arr[s].cost_off, arr[s].out_off, arr[s].Q, arr[s].q_stride = off, s * M, q, st
     off += M * st
