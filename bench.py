@@ -69,6 +69,53 @@ def cpu_baseline(wl, sets, targets, budget_s=20.0):
     }
 
 
+def stress_roofline(device, launches=20):
+    """Cost kernel alone at the cfg4 size (B=256, Q=900, C=91, heavy-tail T, 6 sets: 0.65 GB of
+    algorithmic traffic per launch), the size at which an HBM-roofline fraction is meaningful.
+    Timed with events on the launch stream over back-to-back launches through the C ABI."""
+    import detr_amd
+    from detr_amd import synth
+    from detr_amd._lib import DmSet, lib
+    from detr_amd.matcher import PackedTargets
+
+    wl, sets, targets = synth.make_workload("cfg4", device=device)
+    packed = PackedTargets(targets, device)
+    S, M = len(sets), packed.total
+    arr = (DmSet * S)()
+    off = 0
+    for s, o in enumerate(sets):
+        q = o["pred_logits"].shape[1]
+        stride = (q + 31) & ~31
+        arr[s].logits, arr[s].boxes = o["pred_logits"].data_ptr(), o["pred_boxes"].data_ptr()
+        arr[s].cost_off, arr[s].out_off, arr[s].Q, arr[s].q_stride = off, s * M, q, stride
+        off += M * stride
+    cost = torch.empty(off, dtype=torch.float32, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    prm = detr_amd.HungarianMatcher(**wl.matcher_kwargs)._params()
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def launch():
+        rc = lib.dm_cost_f32(arr, S, packed.batch, wl.n_logits, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                             packed.offsets_ptr, packed.max_t, ctypes.byref(prm), cost.data_ptr(),
+                             status.data_ptr(), stream)
+        assert rc == 0, rc
+
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        launch()
+    e1.record()
+    torch.cuda.synchronize(device)
+    ms = e0.elapsed_time(e1) / launches
+    algo = cost_kernel_bytes(wl.set_queries, wl.n_logits, packed.sizes)
+    achieved = algo / (ms * 1e-3) / 1e9
+    return {"workload": "cfg4 cost kernel only: B=256, Q=900, C=91, heavy-tail T, 6 sets", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel": "cost_tile_kernel", "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +124,10 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stress", action="store_true", help="skip the cfg4-size cost-kernel measurement")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); gloo for rehearsals")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,11 +135,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import detr_amd
     from detr_amd import synth
@@ -109,7 +165,10 @@ def main():
     def fence():
         torch.cuda.synchronize(device)
         if world > 1:
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
@@ -163,9 +222,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "cost_kernel", "algorithmic_bytes_per_step": algo_bytes,
                          "ms_per_step_hip_events": cost_ms_avg},
-            "lap": {"kernel": "lap_wave_kernel", "ms_per_step_hip_events": lap_ms_avg,
+            "lap": {"kernel": "lap_block_kernel / lap_wave_kernel", "ms_per_step_hip_events": lap_ms_avg,
                     "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
         }
+        if world == 1 and not args.no_stress:
+            record["roofline_stress"] = stress_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             record["cpu_baseline"] = cpu_baseline(wl, sets, targets)
         print(json.dumps(record), flush=True)
