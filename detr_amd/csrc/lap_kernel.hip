@@ -400,13 +400,43 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
     for (int k = 0; k < NCOL; ++k) emit_pair(r4c[k] >= 0, lane + 64 * k, r4c[k], base, lane, so, to);
 }
 
+// Inverse of sortable_words.
+__device__ __forceinline__ double from_sortable_words(unsigned hi, unsigned lo)
+{
+    const unsigned m = (hi & 0x80000000u) ? 0u : 0xFFFFFFFFu;    // top bit set <=> value was non-negative
+    return __hiloint2double((int)(hi ^ (m | 0x80000000u)), (int)(lo ^ m));
+}
+
+// Lanes of `cand` whose (hi, lo[, key]) is the lexicographic minimum (key: maximum); returns
+// the lane mask after as few 32-bit wave reductions as the data needs.
+__device__ __forceinline__ unsigned long long narrow_to_minimum(bool cand, unsigned hi, unsigned lo, unsigned key)
+{
+    const unsigned mhi = dm::wave_min_u32(cand ? hi : 0xFFFFFFFFu);
+    bool mine = cand && hi == mhi;
+    unsigned long long at = __ballot(mine);
+    if (__popcll(at) > 1) {
+        const unsigned mlo = dm::wave_min_u32(mine ? lo : 0xFFFFFFFFu);
+        mine = mine && lo == mlo;
+        at = __ballot(mine);
+        if (__popcll(at) > 1) {
+            const unsigned K = dm::wave_max_u32(mine ? key : 0u);
+            mine = mine && key == K;
+            at = __ballot(mine);
+        }
+    }
+    return at;
+}
+
 // One workgroup of W wavefronts (W = blockDim.x / 64, 1..16) per problem with T < Q <= 64*W*NCOL.
 // Thread `tid` owns the columns (queries) j = tid + 64*W*k, k < NCOL, and keeps their reduced
-// cost, dual, assignment, predecessor and list position in registers.  Per Dijkstra step:
-// every wave reduces its own columns with DPP (minimum, then the tie key among the minima),
-// lane 0 publishes (min, key, column, assigned row) in LDS, one barrier, and every wave
-// reduces the W published records again -- so all waves agree on the step's column without a
-// second barrier (the records are double-buffered by step parity).
+// cost, dual, assignment, predecessor and list position in registers; scanned columns are
+// parked (reduced cost +inf, dual -inf) as in lap_wave_kernel.  Per Dijkstra step every wave
+// narrows its columns to one candidate with 32-bit DPP reductions on order-preserving words,
+// the candidate's lane publishes one record in LDS, ONE barrier, and every wave narrows the W
+// records the same way -- all waves agree on the step's column without a second barrier (the
+// records are double-buffered by step parity).  State that every wave needs (list, row
+// assignment of a one-step row) is written redundantly by each wave, so a wave only ever
+// depends on its own LDS writes between barriers.
 template <int NCOL>
 __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL)) void lap_block_kernel(const DmSetArray sets, const int S,
                                                          const float *__restrict__ cost,
@@ -416,6 +446,7 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
                                                          int32_t *status, const int t_cap, const int lds_cost_floats)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    constexpr double NEG_INF = -INF;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int BS = blockDim.x, W = BS >> 6;
@@ -430,12 +461,11 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
 
     double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
-    double *sval = u + t_cap;                               // [2][16] published wave minima
-    unsigned *skey = reinterpret_cast<unsigned *>(sval + 32);   // [2][16] tie keys
-    int *sj = reinterpret_cast<int *>(skey + 32);           // [2][16] column of the wave's candidate
-    int *sr = sj + 32;                                      // [2][16] row assigned to that column, or -1
-    int *col4row = sr + 32;                                 // [t_cap]
-    int *row4col = col4row + t_cap;                         // [QCAP]
+    uint4 *rec = reinterpret_cast<uint4 *>(u + t_cap);      // [2][16] published candidates: hi, lo, key, column
+    int *recr = reinterpret_cast<int *>(rec + 32);          // [2][16] row assigned to that column, or -1
+    int *col4row = recr + 32;                               // [t_cap]
+    int *sclist = col4row + t_cap;                          // [t_cap] columns scanned in the current row, in order
+    int *row4col = sclist + t_cap;                          // [QCAP]
     int *pathL = row4col + QCAP;                            // [QCAP]
     int *remaining = pathL + QCAP;                          // [QCAP] list position -> column
     float *crow = reinterpret_cast<float *>(remaining + QCAP);   // [lds_cost_floats] first rows of the block
@@ -447,25 +477,25 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
     const int ls = linear ? qs : nc;                        // LDS row stride
     const int R = min(nr, lds_cost_floats / ls);            // rows resident in LDS
 
-    double v[NCOL], spc[NCOL];
+    double v[NCOL], spc[NCOL], v_real[NCOL], spc_real[NCOL];
     int r4c[NCOL], pth[NCOL], jc[NCOL], posr[NCOL];
-    unsigned valid = 0;
 #pragma unroll
     for (int k = 0; k < NCOL; ++k) {
         const int j = tid + BS * k;
-        v[k] = 0.0; spc[k] = INF; r4c[k] = -1; pth[k] = -1;
-        jc[k] = min(j, nc - 1);      // columns past the end alias the last one and are never live
+        const bool ok = j < nc;
+        v[k] = ok ? 0.0 : NEG_INF;
+        spc[k] = INF; v_real[k] = 0.0; spc_real[k] = INF; r4c[k] = -1; pth[k] = -1;
+        jc[k] = min(j, nc - 1);      // columns past the end alias the last one and stay parked
         posr[k] = nc - 1 - j;
-        if (j < nc) {
-            valid |= 1u << k;
+        if (ok) {
             row4col[j] = -1;
             remaining[nc - 1 - j] = j;
         }
     }
     for (int i = tid; i < nr; i += BS) { u[i] = 0.0; col4row[i] = -1; }
 
-    // Stage the first R rows in LDS.  A dense, 16-byte aligned block goes through LDS-DMA
-    // (no registers, every piece in flight at once); anything else through registers.
+    // Stage the first R rows in LDS.  A 16-byte aligned block goes through LDS-DMA (no
+    // registers, every piece in flight at once); anything else through registers.
     const int nfl = R * ls;
     bool bad = false;
     if (linear) {
@@ -502,16 +532,14 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
 
     int par = 0;
     for (int cur = 0; cur < nr; ++cur) {
-        unsigned sc = 0;            // own columns already scanned (in the tree)
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
 
-        while (true) {
+        while (n > 0) {      // every step parks one column: at most nc steps
             const double ui = u[i];
-            const bool in_lds = i < R;
-            const unsigned live = valid & ~sc;
+            const int jl_read = remaining[n - 1];     // column at the last list position
             float c[NCOL];
-            if (in_lds) {
+            if (i < R) {
                 const float *row = crow + i * ls;
 #pragma unroll
                 for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
@@ -529,99 +557,131 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
             double lmin = INF;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const double r = ((min_val + (double)c[k]) - ui) - v[k];
-                const bool lv = (live >> k) & 1u;
-                const bool better = lv && (r < spc[k]);
+                const double r = ((min_val + (double)c[k]) - ui) - v[k];   // +inf for parked columns
+                const bool better = r < spc[k];
                 spc[k] = better ? r : spc[k];
                 pth[k] = better ? i : pth[k];
-                lmin = lv ? fmin(lmin, spc[k]) : lmin;
+                lmin = fmin(lmin, spc[k]);
             }
-            const double wm = dm::wave_min_f64(lmin);
-            // the wave's candidate under the list-position rule
+            // the lane's candidate among its own columns (list-position rule on ties)
             unsigned key = 0;
             int cj = -1, cr = -1;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const bool hit = ((live >> k) & 1u) && (spc[k] == wm);
+                const bool hit = NCOL == 1 || spc[k] == lmin;
                 const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
                 if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
             }
-            const unsigned wk = dm::wave_max_u32(key);
-            if (wk != 0 && key == wk) {     // exactly one lane: keys are unique
-                sval[par * 16 + wave] = wm;
-                skey[par * 16 + wave] = wk;
-                sj[par * 16 + wave] = cj;
-                sr[par * 16 + wave] = cr;
-            } else if (wk == 0 && lane == 0) {
-                sval[par * 16 + wave] = INF;
-                skey[par * 16 + wave] = 0;
+            unsigned hi, lo;
+            sortable_words(lmin, hi, lo);
+            // the wave's candidate, published by its lane
+            const unsigned long long at = narrow_to_minimum(true, hi, lo, key);
+            if (lane == __ffsll((long long)at) - 1) {
+                rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj);
+                recr[par * 16 + wave] = cr;
             }
             __syncthreads();
-            const int sl = par * 16 + (lane < W ? lane : 0);
-            const double x = lane < W ? sval[sl] : INF;
-            unsigned kx = lane < W ? skey[sl] : 0u;
-            const double m = dm::wave_min_f64(x);
+            // every wave picks the workgroup's candidate from the W records
+            const bool has = lane < W;
+            const uint4 x = rec[par * 16 + (has ? lane : 0)];
+            const int xr = recr[par * 16 + (has ? lane : 0)];
+            const unsigned long long win = narrow_to_minimum(has, x.x, x.y, x.z);
+            const int wl = __ffsll((long long)win) - 1;
+            const unsigned whi = (unsigned)dm::readlane_i32((int)x.x, wl);
+            const unsigned wlo = (unsigned)dm::readlane_i32((int)x.y, wl);
+            const unsigned K = (unsigned)dm::readlane_i32((int)x.z, wl);
+            const int jw = dm::readlane_i32((int)x.w, wl);
+            const int rw = dm::readlane_i32(xr, wl);
+            const double m = from_sortable_words(whi, wlo);
             if (!(m < INF)) {
                 if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
                 return;
             }
-            kx = (x == m) ? kx : 0u;
-            const unsigned K = dm::wave_max_u32(kx);
-            const int wv = __ffsll((long long)__ballot(kx == K && lane < W)) - 1;
-            const int jw = __builtin_amdgcn_readfirstlane(sj[par * 16 + wv]);
-            const int rw = __builtin_amdgcn_readfirstlane(sr[par * 16 + wv]);
             const int pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
-            // swap-with-last removal of column jw from the remaining list
-            const int jl = __builtin_amdgcn_readfirstlane(remaining[n - 1]);
+            // swap-with-last removal of column jw (every wave writes the same values)
+            const int jl = __builtin_amdgcn_readfirstlane(jl_read);
+            if (lane == 0) {
+                remaining[pw] = jl;
+                sclist[nc - n] = jw;
+            }
             --n;
-            if (tid == 0) remaining[pw] = jl;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
                 const int j = tid + BS * k;
                 posr[k] = (j == jl) ? pw : posr[k];
-                if (j == jw) sc |= 1u << k;
+                if (j == jw) {       // park the column in its owner's registers
+                    spc_real[k] = spc[k]; v_real[k] = v[k];
+                    spc[k] = INF; v[k] = NEG_INF;
+                }
             }
             par ^= 1;
             min_val = m;
             if (rw == -1) { sink = jw; break; }
             i = rw;
         }
+        if (sink < 0) {      // ran out of columns without reaching an unassigned one
+            if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
+            return;
+        }
 
-        // dual update, then publish the predecessors of the scanned columns
+        // Row end: dual update of the scanned columns, augmentation along the predecessor
+        // chain, un-parking, and the list back in its initial (reversed) order.
+        const int nsc = nc - n;
+        if (nsc == 1) {
+            // the first step already found an unassigned column: nothing changes but u[cur].
+            // No barrier: every wave writes the shared words itself.
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) {
-            if ((sc >> k) & 1u) {
+            for (int k = 0; k < NCOL; ++k) {
                 const int j = tid + BS * k;
-                const double d = min_val - spc[k];
-                if (j != sink) u[r4c[k]] += d;
-                v[k] -= d;
-                pathL[j] = pth[k];
+                if (j == sink) { r4c[k] = cur; v[k] = v_real[k]; }
+                posr[k] = nc - 1 - j;
+                spc[k] = INF;
             }
-        }
-        if (tid == 0) u[cur] += min_val;
-        __syncthreads();
-        if (tid == 0) {
-            int j = sink;
-            for (int guard = 0; guard <= nr; ++guard) {
-                const int ii = pathL[j];
-                row4col[j] = ii;
-                const int jn = col4row[ii];
-                col4row[ii] = j;
-                j = jn;
-                if (ii == cur) break;
+            if (lane == 0) {
+                u[cur] = min_val;                     // it was 0
+                col4row[cur] = sink;
+                row4col[sink] = cur;
+                remaining[nc - 1 - sink] = sink;      // undo the removal (slot nc-1 still holds column 0)
             }
-        }
-        __syncthreads();
-        // refresh the assignments that may have changed, put the list back in its initial order
+        } else {
 #pragma unroll
-        for (int k = 0; k < NCOL; ++k) {
-            const int j = tid + BS * k;
-            if ((sc >> k) & 1u) r4c[k] = row4col[j];
-            spc[k] = INF;
-            posr[k] = nc - 1 - j;
-            if ((valid >> k) & 1u) remaining[nc - 1 - j] = j;
+            for (int k = 0; k < NCOL; ++k) {
+                if (v[k] == NEG_INF && tid + BS * k < nc) {      // a column scanned in this row
+                    const int j = tid + BS * k;
+                    const double d = min_val - spc_real[k];
+                    if (j != sink) u[r4c[k]] += d;
+                    v[k] = v_real[k] - d;
+                    pathL[j] = pth[k];
+                }
+            }
+            if (tid == 0) u[cur] += min_val;
+            __syncthreads();
+            if (tid == 0) {
+                int j = sink;
+                for (int guard = 0; guard <= nr; ++guard) {
+                    const int ii = pathL[j];
+                    row4col[j] = ii;
+                    const int jn = col4row[ii];
+                    col4row[ii] = j;
+                    j = jn;
+                    if (ii == cur) break;
+                }
+            }
+            __syncthreads();
+            // refresh the assignments of the scanned columns; list and positions back to initial
+            for (int e = 0; e < nsc; ++e) {
+                const int j = __builtin_amdgcn_readfirstlane(sclist[e]);
+                const int r = __builtin_amdgcn_readfirstlane(row4col[j]);
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k)
+                    if (tid + BS * k == j) r4c[k] = r;
+                if (lane == 0) remaining[nc - 1 - j] = j;
+            }
+            for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
+            __syncthreads();
         }
-        // (the next step's first read of `remaining` follows that step's barrier)
     }
 
     __syncthreads();
@@ -831,7 +891,7 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const int qcap = 64 * waves * NCOL;
-    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * (8 + 4 + 4 + 4) + (size_t)3 * qcap * 4;
+    const size_t fixed = (size_t)t_cap * (8 + 4 + 4) + 32 * (16 + 4) + (size_t)3 * qcap * 4;
     size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS; many: keep more resident
     const size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : 48 * 1024;
