@@ -36,6 +36,7 @@ constexpr int FAST_MAX_NCOL = 17;
 constexpr int FAST_MAX_Q = 64 * FAST_MAX_NCOL;
 constexpr int GENERIC_MAX = 4096;
 
+int g_lap_max_waves = 16;   // wavefronts per problem in lap_block_kernel (tuning knob)
 int g_lap_mode = 0;   // 0: automatic; 1: list-order kernel only; 2: workgroup kernel; 3: wavefront kernel
 
 // Diagnostic build only (-DDM_LAP_STAMPS): cycle stamps around the segments of a step.
@@ -459,6 +460,12 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
     const int t0 = tgt_off[b];
     const int nr = tgt_off[b + 1] - t0;   // rows = targets
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
+#ifdef DM_LAP_STAMPS
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_c1 = 0;
+    int st_iters = 0;
+    unsigned long long st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
+#endif
 
     double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
     uint4 *rec = reinterpret_cast<uint4 *>(u + t_cap);      // [2][16] published candidates: hi, lo, key, column
@@ -507,8 +514,8 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int i = 0; i < R; ++i)      // (the padding behind column nc is never written: skip it)
-            for (int e = tid * 4; e < nc; e += BS * 4) {
+        for (int i = wave; i < R; i += W)      // one row per wave and trip (the padding behind column nc is
+            for (int e = lane * 4; e < nc; e += 256) {      // never written: skip it)
                 const float4 x = *reinterpret_cast<const float4 *>(crow + i * ls + e);
                 bad |= cost_is_invalid(x.x) | (e + 1 < nc && cost_is_invalid(x.y)) |
                        (e + 2 < nc && cost_is_invalid(x.z)) | (e + 3 < nc && cost_is_invalid(x.w));
@@ -530,12 +537,18 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
         return;
     }
 
+#ifdef DM_LAP_STAMPS
+    st_c1 = __builtin_amdgcn_s_memtime();
+#endif
     int par = 0;
     for (int cur = 0; cur < nr; ++cur) {
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
 
         while (n > 0) {      // every step parks one column: at most nc steps
+#ifdef DM_LAP_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
+#endif
             const double ui = u[i];
             const int jl_read = remaining[n - 1];     // column at the last list position
             float c[NCOL];
@@ -554,6 +567,7 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
                     if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
                 }
             }
+            DM_STAMP(0)
             double lmin = INF;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
@@ -574,13 +588,16 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
             }
             unsigned hi, lo;
             sortable_words(lmin, hi, lo);
+            DM_STAMP(1)
             // the wave's candidate, published by its lane
             const unsigned long long at = narrow_to_minimum(true, hi, lo, key);
             if (lane == __ffsll((long long)at) - 1) {
                 rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj);
                 recr[par * 16 + wave] = cr;
             }
+            DM_STAMP(2)
             __syncthreads();
+            DM_STAMP(3)
             // every wave picks the workgroup's candidate from the W records
             const bool has = lane < W;
             const uint4 x = rec[par * 16 + (has ? lane : 0)];
@@ -616,6 +633,10 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
             }
             par ^= 1;
             min_val = m;
+            DM_STAMP(4)
+#ifdef DM_LAP_STAMPS
+            ++st_iters;
+#endif
             if (rw == -1) { sink = jw; break; }
             i = rw;
         }
@@ -685,6 +706,14 @@ __global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1)
     }
 
     __syncthreads();
+#ifdef DM_LAP_STAMPS
+    if (tid == 0) {
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime(), r2 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *rec2 = reinterpret_cast<unsigned long long *>(status + 16) + (size_t)blockIdx.x * 12;
+        rec2[0] = st_c1 - st_c0; rec2[1] = c2 - st_c1; rec2[2] = r2 - st_r0; rec2[3] = st_iters; rec2[4] = nr; rec2[5] = c2 - st_c0;
+        for (int q = 0; q < 5; ++q) rec2[6 + q] = st_seg[q];
+    }
+#endif
     if (wave == 0) {
         int64_t *so = src_out + set.out_off + t0;
         int64_t *to = tgt_out + set.out_off + t0;
@@ -875,7 +904,7 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
     long long w = need;
     const long long wave_budget = 6144;                // about 24 wavefronts per CU
     if (P * need > wave_budget) w = wave_budget / P;
-    if (w > 16) w = 16;
+    if (w > g_lap_max_waves) w = g_lap_max_waves;
     if (w < 1) w = 1;
     int n = (need + (int)w - 1) / (int)w;
     for (int c : NCOL_CLASSES) if (c >= n) { n = c; break; }
@@ -929,7 +958,11 @@ int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, c
 // Testing aid: 0 restores the automatic choice of assignment kernel, 1 routes every problem
 // through the list-order kernel, 2 / 3 force the workgroup / wavefront register kernel for
 // the problems they can take.
-extern "C" void dm_debug_force_generic_lap(int mode) { g_lap_mode = mode; }
+extern "C" void dm_debug_force_generic_lap(int mode)
+{
+    if (mode >= 100) { g_lap_max_waves = mode - 100; return; }    // 101..116: wavefronts per problem
+    g_lap_mode = mode;
+}
 
 extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
                           const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out,

@@ -54,5 +54,5 @@ A = np.stack([rec[:, 3], rec[:, 4], np.ones(len(rec))], 1)
 coef, *_ = np.linalg.lstsq(A, rec[:, 1], rcond=None)
 print("least squares: cycles = %.0f * steps + %.0f * rows + %.0f" % tuple(coef))
 seg = rec[:, 6:11] / rec[:, 3:4]
-print("per-step segment cycles (median): loads %.0f | scan %.0f | locate min %.0f | candidates %.0f | bookkeeping %.0f" % tuple(np.median(seg, 0)))
+print("per-step segment cycles (median): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f" % tuple(np.median(seg, 0)))
 print("sum of segments per step %.0f ; row-end etc per row %.0f" % (np.median(seg.sum(1)), np.median((rec[:, 1] - rec[:, 6:11].sum(1)) / rec[:, 4])))
