@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                                                             const int64_t *__restrict__ labels,
                                                             const float *__restrict__ tboxes,
                                                             const int32_t *__restrict__ tgt_off, const DmParams prm,
-                                                            float *__restrict__ cost, int32_t *status)
+                                                            float *__restrict__ cost, int32_t *status, const int tsplit)
 {
     __shared__ TgtRec tg[TCHUNK];
     typedef float vecq __attribute__((ext_vector_type(QPT)));
@@ -153,10 +153,16 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
     const DmSet &set = sets.s[blockIdx.z];
     const int b = blockIdx.y;
     const int Q = set.Q;
-    const int q0 = (blockIdx.x * blockDim.x + threadIdx.x) * QPT;     // first query of this thread
-    if ((int)(blockIdx.x * blockDim.x) * QPT >= Q) return;
-    const int t0 = tgt_off[b];
-    const int T = tgt_off[b + 1] - t0;
+    // blockIdx.x = query tile * tsplit + target slice: with few problems in flight the targets of
+    // an image are split over `tsplit` workgroups to shorten every thread's serial loop
+    const int tile = blockIdx.x / tsplit, slice = blockIdx.x - tile * tsplit;
+    const int q0 = (tile * blockDim.x + threadIdx.x) * QPT;     // first query of this thread
+    if ((int)(tile * blockDim.x) * QPT >= Q) return;
+    const int t_all0 = tgt_off[b];
+    const int T_all = tgt_off[b + 1] - t_all0;
+    const int per = (T_all + tsplit - 1) / tsplit;
+    const int t0 = t_all0 + min(slice * per, T_all);
+    const int T = min(per, t_all0 + T_all - t0);
 
     // own prediction boxes and logits (clamped to the last query when past the end); the
     // reference validates every prediction of the batch
@@ -179,8 +185,8 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
         p[i] = make_pred(raw[i]);
         ok = ok && (pred_valid(p[i]) || q0 + i >= Q);
     }
-    if (!ok) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
-    if (T == 0) return;
+    if (!ok && slice == 0) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+    if (T <= 0) return;
 
     // cost_class * class cost of every class, once per query
     float wc[QPT][C];
@@ -372,6 +378,7 @@ int pick_waves(int Q, int max_waves)
 
 thread_local char g_hip_err[256] = "";
 int g_cost_dbg = 0;   // diagnostic kernel variants (timing only, wrong results)
+int g_cost_tsplit = 0;   // 0: automatic; otherwise forced target split (testing aid)
 int g_cost_qpt = 0;   // 0: automatic; 1 / 2: force the queries-per-thread variant (testing aid)
 
 }  // namespace
@@ -382,6 +389,7 @@ extern "C" const char *dm_last_hip_error(void) { return g_hip_err; }
 // the small-C cost kernel.
 extern "C" void dm_debug_cost_queries_per_thread(int qpt)
 {
+    if (qpt >= 200) { g_cost_tsplit = qpt - 200; return; }   // 201, 202, 204: forced target split
     g_cost_dbg = qpt >= 100 ? qpt - 100 : 0;      // 101..103: timing-only variants of the C = 2 kernel
     g_cost_qpt = (qpt == 1 || qpt == 2) ? qpt : 0;
 }
@@ -438,17 +446,23 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
                     const int qpt = g_cost_qpt ? g_cost_qpt : 1;
                     const int lanes = (Q + qpt - 1) / qpt;
                     const int threads = 64 * pick_waves(lanes, 8);
-                    dim3 grid((lanes + threads - 1) / threads, B, n);
+                    // few wavefronts in flight: split every image's targets over 2 or 4 workgroups
+                    const long long waves_total = (long long)((lanes + 63) / 64) * B * n;
+                    int tsplit = 1;      // measured on MI355X: 4-way below ~1k wavefronts, 2-way below ~8k
+                    if (waves_total <= 1024 && max_T >= 8) tsplit = 4;
+                    else if (waves_total <= 8192 && max_T >= 4) tsplit = 2;
+                    if (g_cost_tsplit) tsplit = g_cost_tsplit;
+                    dim3 grid(((lanes + threads - 1) / threads) * tsplit, B, n);
 #define DM_LAUNCH_SMALL(CC, QQ)                                                                                  \
     hipLaunchKernelGGL((cost_small_kernel<CC, QQ>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, \
-                       *params, cost, status)
+                       *params, cost, status, tsplit)
                     if (qpt == 1) {
                         switch (C) {
                         case 1: DM_LAUNCH_SMALL(1, 1); break;
                         case 2:
-                            if (g_cost_dbg == 1) hipLaunchKernelGGL((cost_small_kernel<2, 1, 1>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status);
-                            else if (g_cost_dbg == 2) hipLaunchKernelGGL((cost_small_kernel<2, 1, 2>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status);
-                            else if (g_cost_dbg == 3) hipLaunchKernelGGL((cost_small_kernel<2, 1, 3>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status);
+                            if (g_cost_dbg == 1) hipLaunchKernelGGL((cost_small_kernel<2, 1, 1>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status, tsplit);
+                            else if (g_cost_dbg == 2) hipLaunchKernelGGL((cost_small_kernel<2, 1, 2>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status, tsplit);
+                            else if (g_cost_dbg == 3) hipLaunchKernelGGL((cost_small_kernel<2, 1, 3>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status, tsplit);
                             else DM_LAUNCH_SMALL(2, 1);
                             break;
                         case 3: DM_LAUNCH_SMALL(3, 1); break;
