@@ -1,0 +1,116 @@
+"""Randomised GPU parity: arbitrary small shapes (T = 0, T > Q, C on both sides of the
+register/LDS-tile split, odd and even C), both class costs, random weights -- each checked against
+scipy on the GPU's own cost (bit-exact) and against the CPU oracle (tie-tolerant)."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+from scipy.optimize import linear_sum_assignment
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(rng, n):
+    return np.concatenate([rng.random((n, 2)), rng.random((n, 2)) * 0.3 + 0.01], axis=1).astype(np.float32)
+
+
+@st.composite
+def problems(draw):
+    B = draw(st.integers(1, 5))
+    Q = draw(st.sampled_from([1, 2, 5, 17, 63, 64, 65, 100, 130, 257]))
+    C = draw(st.sampled_from([1, 2, 3, 4, 5, 8, 11, 80, 91]))
+    sizes = [draw(st.sampled_from([0, 0, 1, 2, 3, 7, 16, 40, 70])) for _ in range(B)]
+    cls = draw(st.sampled_from(["ce", "focal"]))
+    w = (draw(st.sampled_from([0.0, 1.0, 2.0])), draw(st.sampled_from([0.0, 1.0, 5.0])),
+         draw(st.sampled_from([0.0, 2.0])))
+    if w == (0.0, 0.0, 0.0):
+        w = (1.0, 5.0, 2.0)
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    return B, Q, C, sizes, cls, w, seed
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(problems())
+def test_random_problems_match_oracle_and_scipy(p):
+    import detr_amd
+    from oracle import oracle
+
+    B, Q, C, sizes, cls, w, seed = p
+    rng = np.random.default_rng(seed)
+    logits = (rng.standard_normal((B, Q, C)) * 2).astype(np.float32)
+    pboxes = _boxes(rng, B * Q).reshape(B, Q, 4)
+    labels = [rng.integers(0, C, t).astype(np.int64) for t in sizes]
+    tboxes = [_boxes(rng, t) for t in sizes]
+    kw = dict(cls_loss=cls, cost_class=w[0], cost_bbox=w[1], cost_giou=w[2], focal_alpha=0.25, focal_gamma=2.0)
+
+    outputs = {"pred_logits": torch.from_numpy(logits).cuda(), "pred_boxes": torch.from_numpy(pboxes).cuda()}
+    targets = [{"labels": torch.from_numpy(l).cuda(), "boxes": torch.from_numpy(b).cuda()}
+               for l, b in zip(labels, tboxes)]
+    matcher = detr_amd.HungarianMatcher(**kw)
+    got = matcher(outputs, targets)
+    blocks = matcher.cost_blocks(outputs, targets)
+    ref, ref_cost = oracle.match(logits, pboxes, labels, tboxes, return_cost=True, **kw)
+    assert len(got) == B
+    for b in range(B):
+        n = min(Q, sizes[b])
+        gs, gt = got[b][0].numpy(), got[b][1].numpy()
+        assert gs.shape == (n,) and gt.shape == (n,) and gs.dtype == np.int64
+        if n == 0:
+            continue
+        blk = blocks[b].cpu().numpy()
+        golden_io.assert_cost_close(blk, ref_cost[b], logits[b], labels[b], cls, w[0], 0.25, 2.0)
+        rs, cs = linear_sum_assignment(blk)
+        np.testing.assert_array_equal(gs, rs)
+        np.testing.assert_array_equal(gt, cs)
+        if not (np.array_equal(gs, ref[b][0]) and np.array_equal(gt, ref[b][1])):
+            a = golden_io.assignment_cost(ref_cost[b], gs, gt)
+            r = golden_io.assignment_cost(ref_cost[b], ref[b][0], ref[b][1])
+            assert abs(a - r) <= 1e-5 * max(1.0, abs(r))
+
+
+def test_non_contiguous_and_offset_inputs():
+    """Views with strides / storage offsets are accepted and give the same answer."""
+    import detr_amd
+
+    g = golden_io.load("focal_c2_q50")
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    base = matcher(outputs, targets)
+    big_logits = torch.zeros(g.B, g.Q, g.C + 3, device="cuda")
+    big_logits[..., 1:1 + g.C] = outputs["pred_logits"]
+    big_boxes = torch.zeros(g.B, g.Q + 1, 5, device="cuda")
+    big_boxes[:, 1:, 1:] = outputs["pred_boxes"]
+    views = {"pred_logits": big_logits[..., 1:1 + g.C], "pred_boxes": big_boxes[:, 1:, 1:]}
+    assert not views["pred_logits"].is_contiguous()
+    got = matcher(views, targets)
+    for (a0, a1), (b0, b1) in zip(base, got):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_match_many_equals_per_set_calls():
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg3_hw", device="cuda", batch=6)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    packed = detr_amd.PackedTargets(targets, torch.device("cuda", 0))
+    many = matcher.match_many(sets, packed)
+    for s, out in enumerate(sets):
+        single = matcher(out, targets)
+        for (a0, a1), (b0, b1) in zip(single, many[s]):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_dtype_and_shape_errors():
+    import detr_amd
+
+    g = golden_io.load("ce_c3_q50")
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    with pytest.raises(RuntimeError):
+        matcher({"pred_logits": outputs["pred_logits"].double(), "pred_boxes": outputs["pred_boxes"]}, targets)
+    with pytest.raises(ValueError):
+        matcher(outputs, targets[:-1])
