@@ -5,8 +5,8 @@ the work is done by two hand-written HIP kernels in ``libdetr_match.so`` (C ABI 
 ``include/detr_match.h``).  Importing the package fails if that library has not been built.
 """
 from ._lib import LIB_PATH, lib  # noqa: F401  (fails loudly when the extension is missing)
-from .matcher import HungarianMatcher, PackedTargets  # noqa: F401
+from .matcher import FlatMatches, HungarianMatcher, PackedTargets  # noqa: F401
 from .lsap import batched_linear_sum_assignment  # noqa: F401
 from . import dist, synth  # noqa: F401
 
-__all__ = ["HungarianMatcher", "PackedTargets", "batched_linear_sum_assignment", "dist", "synth", "LIB_PATH"]
+__all__ = ["HungarianMatcher", "PackedTargets", "FlatMatches", "batched_linear_sum_assignment", "dist", "synth", "LIB_PATH"]

@@ -140,7 +140,7 @@ __device__ __forceinline__ void stage_targets(TgtRec *tg, const int64_t *__restr
 
 // C <= 4.  Every thread owns QPT consecutive queries of one image and loops over the image's
 // targets; the QPT costs of a target go out as one QPT*4-byte store.
-template <int C, int QPT, int DBG = 0>
+template <int C, int QPT>
 __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray sets,
                                                             const int64_t *__restrict__ labels,
                                                             const float *__restrict__ tboxes,
@@ -220,7 +220,6 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
         }
         __syncthreads();
         if (q0 < Q) {
-            float dbg_acc = 0.0f;
             TgtRec g = tg[0];
             for (int i = 0; i < nt; ++i) {
                 const TgtRec gn = tg[min(i + 1, nt - 1)];     // next record in flight while this one is used
@@ -234,12 +233,10 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                     float wcls = wc[k][0];
 #pragma unroll
                     for (int c = 1; c < C; ++c) wcls = (l == c) ? wc[k][c] : wcls;
-                    r[k] = (DBG & 2) ? wcls + g.area : pair_cost(p[k], g, wcls, prm.w_bbox, prm.w_giou);
+                    r[k] = pair_cost(p[k], g, wcls, prm.w_bbox, prm.w_giou);
                 }
                 float *dst = out + (size_t)(tc + i) * qs;
-                if (DBG & 1) {       // diagnostic variant: no store per pair
-                    dbg_acc += r[0];
-                } else if (QPT == 1 || wide) {
+                if (QPT == 1 || wide) {
                     *reinterpret_cast<vecq *>(dst) = r;
                 } else {
 #pragma unroll
@@ -247,7 +244,6 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                 }
                 g = gn;
             }
-            if ((DBG & 1) && dbg_acc == 12345.678f) out[0] = dbg_acc;
         }
     }
 }
@@ -377,7 +373,6 @@ int pick_waves(int Q, int max_waves)
 }
 
 thread_local char g_hip_err[256] = "";
-int g_cost_dbg = 0;   // diagnostic kernel variants (timing only, wrong results)
 int g_cost_tsplit = 0;   // 0: automatic; otherwise forced target split (testing aid)
 int g_cost_qpt = 0;   // 0: automatic; 1 / 2: force the queries-per-thread variant (testing aid)
 
@@ -390,7 +385,6 @@ extern "C" const char *dm_last_hip_error(void) { return g_hip_err; }
 extern "C" void dm_debug_cost_queries_per_thread(int qpt)
 {
     if (qpt >= 200) { g_cost_tsplit = qpt - 200; return; }   // 201, 202, 204: forced target split
-    g_cost_dbg = qpt >= 100 ? qpt - 100 : 0;      // 101..103: timing-only variants of the C = 2 kernel
     g_cost_qpt = (qpt == 1 || qpt == 2) ? qpt : 0;
 }
 
@@ -459,12 +453,7 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
                     if (qpt == 1) {
                         switch (C) {
                         case 1: DM_LAUNCH_SMALL(1, 1); break;
-                        case 2:
-                            if (g_cost_dbg == 1) hipLaunchKernelGGL((cost_small_kernel<2, 1, 1>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status, tsplit);
-                            else if (g_cost_dbg == 2) hipLaunchKernelGGL((cost_small_kernel<2, 1, 2>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status, tsplit);
-                            else if (g_cost_dbg == 3) hipLaunchKernelGGL((cost_small_kernel<2, 1, 3>), grid, dim3(threads), 0, st, arr, tgt_labels, tgt_boxes, tgt_off, *params, cost, status, tsplit);
-                            else DM_LAUNCH_SMALL(2, 1);
-                            break;
+                        case 2: DM_LAUNCH_SMALL(2, 1); break;
                         case 3: DM_LAUNCH_SMALL(3, 1); break;
                         default: DM_LAUNCH_SMALL(4, 1); break;
                         }

@@ -65,6 +65,72 @@ class PackedTargets:
         staged.numpy()[:] = meta
         self.meta = staged.to(device, non_blocking=True)
 
+    @classmethod
+    def from_host(cls, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device) -> "PackedTargets":
+        """Pack targets that are still on the CPU (what the reference's collate function yields,
+        /root/reference/datasets/transforms.py:104-108) and move them with ONE upload instead
+        of the 2B per-tensor copies of /root/reference/train.py:71."""
+        self = cls.__new__(cls)
+        self.sizes = [int(t["boxes"].shape[0]) for t in targets]
+        self.batch = len(self.sizes)
+        self.total = sum(self.sizes)
+        self.max_t = max(self.sizes) if self.sizes else 0
+        self.device = device
+        B, M = self.batch, max(self.total, 1)
+        n_meta = 2 * B + 1
+        # one pinned byte buffer: [boxes f32 4M | labels int64 M | meta int32 2B+1]; every part starts
+        # on the alignment its element type (and the kernels' 16-byte box loads) needs
+        off_labels = 16 * M
+        off_meta = off_labels + 8 * M
+        staged = torch.empty(off_meta + 4 * n_meta, dtype=torch.uint8, pin_memory=True)
+        host_boxes = staged[:off_labels].view(torch.float32).view(M, 4)
+        host_labels = staged[off_labels:off_meta].view(torch.int64)
+        host_meta = staged[off_meta:off_meta + 4 * n_meta].view(torch.int32)
+        if self.total > 0:
+            for t, n in zip(targets, self.sizes):
+                if int(t["labels"].shape[0]) != n:
+                    raise ValueError("a target's labels and boxes differ in length")
+                if t["boxes"].dtype != torch.float32:
+                    raise RuntimeError(f"target boxes must be float32, got {t['boxes'].dtype}")
+            torch.cat([t["labels"].to(torch.int64) for t in targets], out=host_labels)
+            torch.cat([t["boxes"].reshape(-1, 4) for t in targets], out=host_boxes)
+        else:
+            host_labels.zero_()
+            host_boxes.zero_()
+        meta = host_meta.numpy()
+        meta[0] = 0
+        np.cumsum(self.sizes, out=meta[1:B + 1])
+        meta[B + 1:] = np.argsort(-np.asarray(self.sizes, dtype=np.int64), kind="stable")
+        self.offsets_host = meta[:B + 1].copy()
+        dev = staged.to(device, non_blocking=True)
+        self.boxes = dev[:off_labels].view(torch.float32).view(M, 4)
+        self.labels = dev[off_labels:off_meta].view(torch.int64)
+        self.meta = dev[off_meta:off_meta + 4 * n_meta].view(torch.int32)
+        return self
+
+    def _pair_maps(self):
+        """Device int64 [M] maps for consumers of flat indices: image of every packed target and the
+        packed position of that image's first target."""
+        if getattr(self, "_maps", None) is None:
+            sizes = np.asarray(self.sizes, dtype=np.int64)
+            both = np.empty((2, max(self.total, 1)), dtype=np.int64)
+            both[:, :] = 0
+            both[0, :self.total] = np.repeat(np.arange(self.batch, dtype=np.int64), sizes)
+            both[1, :self.total] = np.repeat(self.offsets_host[:-1].astype(np.int64), sizes)
+            staged = torch.empty(both.shape, dtype=torch.int64, pin_memory=True)
+            staged.numpy()[:] = both
+            dev = staged.to(self.device, non_blocking=True)
+            self._maps = (dev[0, :self.total], dev[1, :self.total])
+        return self._maps
+
+    @property
+    def batch_index(self) -> torch.Tensor:
+        return self._pair_maps()[0]
+
+    @property
+    def target_base(self) -> torch.Tensor:
+        return self._pair_maps()[1]
+
     @property
     def offsets_ptr(self) -> int:
         return self.meta.data_ptr()
@@ -72,6 +138,44 @@ class PackedTargets:
     @property
     def order_ptr(self) -> int:
         return self.meta.data_ptr() + 4 * (self.batch + 1)
+
+
+class FlatMatches:
+    """The matches of ONE output set as flat device tensors -- what the reference's losses build
+    from the per-image tuples anyway (/root/reference/models/detr/loss.py:71-75, 102-103, 124-125):
+
+        batch_idx, src_idx   -> outputs['pred_boxes'][batch_idx, src_idx], target_cls[batch_idx, src_idx] = ...
+        tgt_idx              per-image target index (the reference's index_j, concatenated)
+        tgt_flat             index into the packed targets: packed.boxes[tgt_flat], packed.labels[tgt_flat]
+
+    Nothing here synchronises with the host."""
+
+    def __init__(self, batch_idx, src_idx, tgt_idx, tgt_flat, packed, queries):
+        self.batch_idx, self.src_idx, self.tgt_idx, self.tgt_flat = batch_idx, src_idx, tgt_idx, tgt_flat
+        self.packed, self.queries = packed, queries
+
+    @property
+    def num_matched(self) -> int:
+        return int(self.src_idx.shape[0])
+
+    def src_permutation_idx(self):
+        """(batch_idx, src_idx), the reference's `_get_src_permutation_idx` (detr/loss.py:71-75)."""
+        return self.batch_idx, self.src_idx
+
+    def target_boxes(self) -> torch.Tensor:
+        """cat([t['boxes'][i] ...]) of detr/loss.py:103."""
+        return self.packed.boxes[self.tgt_flat]
+
+    def target_labels(self) -> torch.Tensor:
+        """cat([t['labels'][i] ...]) of detr/loss.py:124."""
+        return self.packed.labels[self.tgt_flat]
+
+    def target_classes(self, no_object_class: int) -> torch.Tensor:
+        """Dense [B, Q] class map of detr/loss.py:121-125."""
+        dense = torch.full((self.packed.batch, self.queries), no_object_class, dtype=torch.int64,
+                           device=self.src_idx.device)
+        dense[self.batch_idx, self.src_idx] = self.target_labels()
+        return dense
 
 
 def _raise_for_status(bits: int):
@@ -137,6 +241,40 @@ class HungarianMatcher(torch.nn.Module):
             dims.append(int(logits.shape[1]))
         return device, C, keep, dims
 
+    def _launch(self, outputs_list, packed: PackedTargets):
+        """Enqueue the cost and assignment kernels for all output sets on the current stream.
+        Returns the device buffer [src (S*M) | tgt (S*M) | status word], the queries per set, the
+        cost buffer and, per set, (offset, row stride) of its cost region."""
+        S, batch, M = len(outputs_list), packed.batch, packed.total
+        device, C, keep, queries = self._prepare_sets(outputs_list, batch)
+        if packed.device != device:
+            raise ValueError("targets and predictions must be on the same device")
+        if any(q == 0 for q in queries):
+            raise ValueError("an output set has no queries")
+        sets = (DmSet * S)()
+        cost_off = 0
+        strides = []
+        for s, ((logits, boxes), q) in enumerate(zip(keep, queries)):
+            stride = (q + 31) & ~31          # rows start on 128-byte lines
+            sets[s].logits, sets[s].boxes = logits.data_ptr(), boxes.data_ptr()
+            sets[s].cost_off, sets[s].out_off = cost_off, s * M
+            sets[s].Q, sets[s].q_stride = q, stride
+            strides.append((cost_off, stride))
+            cost_off += M * stride
+
+        cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
+        out = torch.zeros(2 * S * M + 1, dtype=torch.int64, device=device)
+        status_ptr = out.data_ptr() + 8 * 2 * S * M
+        params = self._params()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.dm_match_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                                  packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(params),
+                                  cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M, status_ptr, stream)
+        _lib.check(rc, "dm_match_f32")
+        self.last_status = out[-1:]
+        return out, queries, cost, strides
+
     @torch.no_grad()
     def match_many(self, outputs_list: Sequence[Dict[str, torch.Tensor]],
                    targets: Union[PackedTargets, Sequence[Dict[str, torch.Tensor]]],
@@ -152,41 +290,15 @@ class HungarianMatcher(torch.nn.Module):
         S = len(outputs_list)
         if S == 0:
             return []
+        device = outputs_list[0]["pred_logits"].device
         batch = targets.batch if isinstance(targets, PackedTargets) else len(targets)
-        device, C, keep, queries = self._prepare_sets(outputs_list, batch)
         packed = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, device)
         M, sizes = packed.total, packed.sizes
-
-        if batch == 0 or any(q == 0 for q in queries):
-            if any(q == 0 for q in queries) and batch > 0:
-                raise ValueError("an output set has no queries")
+        if batch == 0:
             return [[] for _ in range(S)]
-
-        sets = (DmSet * S)()
-        cost_off = 0
-        strides = []
-        for s, ((logits, boxes), q) in enumerate(zip(keep, queries)):
-            stride = (q + 31) & ~31
-            sets[s].logits, sets[s].boxes = logits.data_ptr(), boxes.data_ptr()
-            sets[s].cost_off, sets[s].out_off = cost_off, s * M
-            sets[s].Q, sets[s].q_stride = q, stride
-            strides.append((cost_off, stride))
-            cost_off += M * stride
-
-        cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
-        # [src (S*M) | tgt (S*M) | status word]
-        out = torch.zeros(2 * S * M + 1, dtype=torch.int64, device=device)
-        status_ptr = out.data_ptr() + 8 * 2 * S * M
-        params = self._params()
-        stream = torch.cuda.current_stream(device).cuda_stream
-        with torch.cuda.device(device):
-            rc = lib.dm_match_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
-                                  packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(params),
-                                  cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M, status_ptr, stream)
-        _lib.check(rc, "dm_match_f32")
+        out, queries, cost, strides = self._launch(outputs_list, packed)
 
         if device_indices:
-            self.last_status = out[-1:]
             result = self._split(out, S, M, sizes, queries, packed.offsets_host)
         else:
             host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
@@ -223,6 +335,36 @@ class HungarianMatcher(torch.nn.Module):
                 n = min(q, t)
                 per_image.append((src_all[lo:lo + n], tgt_all[lo:lo + n]))
             result.append(per_image)
+        return result
+
+    @torch.no_grad()
+    def match_flat(self, outputs_list, targets) -> List["FlatMatches"]:
+        """`match_many` for consumers that want flat device-resident indices: one `FlatMatches`
+        per output set, no device-to-host copy, no synchronisation (input errors surface through
+        `check_status()`)."""
+        S = len(outputs_list)
+        if S == 0:
+            return []
+        device = outputs_list[0]["pred_logits"].device
+        packed = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, device)
+        if packed.batch == 0:
+            return []
+        out, queries, _, _ = self._launch(outputs_list, packed)
+        M, sizes = packed.total, packed.sizes
+        result = []
+        for s, q in enumerate(queries):
+            src = out[s * M:(s + 1) * M]
+            tgt = out[S * M + s * M:S * M + (s + 1) * M]
+            if M == 0 or q >= packed.max_t:
+                batch_idx, base = packed.batch_index, packed.target_base
+            else:
+                # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
+                keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
+                                       for o, t in zip(packed.offsets_host[:-1], sizes)] + [np.zeros(0, np.int64)])
+                keep_dev = torch.from_numpy(keep).to(device)
+                src, tgt = src[keep_dev], tgt[keep_dev]
+                batch_idx, base = packed.batch_index[keep_dev], packed.target_base[keep_dev]
+            result.append(FlatMatches(batch_idx, src, tgt, tgt + base, packed, q))
         return result
 
     def check_status(self):

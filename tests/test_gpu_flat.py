@@ -1,0 +1,117 @@
+"""Flat device-resident matches and one-upload target packing, checked against what the
+reference's criterion derives from the per-image CPU tuples (models/detr/loss.py:71-75,
+97-133): the gather indices, the matched target boxes / labels and the dense class map."""
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+
+def _criterion_view(indices, targets, batch, queries, no_object):
+    """What the reference's losses build from a list of (src, tgt) tuples, computed on the CPU."""
+    batch_idx = torch.cat([torch.full_like(src, b) for b, (src, _) in enumerate(indices)])
+    src_idx = torch.cat([src for src, _ in indices])
+    boxes = torch.cat([t["boxes"].cpu()[j] for t, (_, j) in zip(targets, indices)])
+    labels = torch.cat([t["labels"].cpu()[j] for t, (_, j) in zip(targets, indices)])
+    dense = torch.full((batch, queries), no_object, dtype=torch.int64)
+    dense[batch_idx, src_idx] = labels
+    return batch_idx, src_idx, boxes, labels, dense
+
+
+@pytest.mark.parametrize("name,batch", [("cfg1", 8), ("cfg2", 16), ("cfg3_hw", 6), ("cfg5", 4)])
+def test_match_flat_equals_criterion_view_of_tuples(name, batch):
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    tuples = matcher.match_many(sets, targets)
+    flats = matcher.match_flat(sets, targets)
+    matcher.check_status()
+    assert len(flats) == len(sets)
+    for s, (flat, out) in enumerate(zip(flats, sets)):
+        B, Q, C = out["pred_logits"].shape
+        bi, si, boxes, labels, dense = _criterion_view(tuples[s], targets, B, Q, C - 1)
+        fb, fs = flat.src_permutation_idx()
+        assert fb.is_cuda and fs.is_cuda and fb.dtype == torch.int64
+        assert flat.num_matched == bi.shape[0]
+        assert torch.equal(fb.cpu(), bi) and torch.equal(fs.cpu(), si)
+        assert torch.equal(flat.tgt_idx.cpu(), torch.cat([j for _, j in tuples[s]]))
+        assert torch.equal(flat.target_boxes().cpu(), boxes)
+        assert torch.equal(flat.target_labels().cpu(), labels)
+        assert torch.equal(flat.target_classes(C - 1).cpu(), dense)
+        # the gathers the losses perform give the same tensors either way
+        assert torch.equal(out["pred_boxes"][fb, fs].cpu(), out["pred_boxes"].cpu()[bi, si])
+
+
+def test_match_flat_more_targets_than_queries():
+    """Images with T > Q match only Q of their targets: the flat view drops the unused slots."""
+    import detr_amd
+
+    g = golden_io.load("ce_t_gt_q")
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    tuples = matcher(outputs, targets)
+    flat = matcher.match_flat([outputs], targets)[0]
+    bi, si, boxes, labels, dense = _criterion_view(tuples, targets, g.B, g.Q, g.C - 1)
+    assert torch.equal(flat.batch_idx.cpu(), bi) and torch.equal(flat.src_idx.cpu(), si)
+    assert torch.equal(flat.target_boxes().cpu(), boxes)
+    assert torch.equal(flat.target_labels().cpu(), labels)
+    assert torch.equal(flat.target_classes(g.C - 1).cpu(), dense)
+
+
+def test_match_flat_no_targets_and_status():
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg1", device="cuda", batch=3)
+    empty = [{"labels": t["labels"][:0], "boxes": t["boxes"][:0]} for t in targets]
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    flat = matcher.match_flat(sets[:1], empty)[0]
+    assert flat.num_matched == 0 and flat.target_boxes().shape == (0, 4)
+    Q, C = sets[0]["pred_logits"].shape[1:]
+    assert bool((flat.target_classes(C - 1) == C - 1).all())
+    # an out-of-range label is reported by check_status(), not by the launch
+    bad = [{"labels": t["labels"].clone(), "boxes": t["boxes"]} for t in targets]
+    bad[1]["labels"][0] = C + 5
+    matcher.match_flat(sets[:1], bad)
+    with pytest.raises(IndexError):
+        matcher.check_status()
+
+
+@pytest.mark.parametrize("name,batch", [("cfg2", 16), ("cfg3_hw", 5)])
+def test_packed_targets_from_host(name, batch):
+    """One pinned upload of CPU targets gives the same packed tensors and the same matches as
+    packing targets that were moved to the device one tensor at a time."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    cpu_targets = [{k: v.cpu() for k, v in t.items()} for t in targets]
+    dev = torch.device("cuda", 0)
+    a = detr_amd.PackedTargets(targets, dev)
+    b = detr_amd.PackedTargets.from_host(cpu_targets, dev)
+    assert a.sizes == b.sizes and a.total == b.total and a.max_t == b.max_t
+    assert torch.equal(a.labels, b.labels) and torch.equal(a.boxes, b.boxes) and torch.equal(a.meta, b.meta)
+    np.testing.assert_array_equal(a.offsets_host, b.offsets_host)
+    assert b.boxes.data_ptr() % 16 == 0 and b.meta.data_ptr() % 4 == 0
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    ra, rb = matcher.match_many(sets, a), matcher.match_many(sets, b)
+    for sa, sb in zip(ra, rb):
+        for (a0, a1), (b0, b1) in zip(sa, sb):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_packed_targets_from_host_empty_batch_member():
+    import detr_amd
+
+    dev = torch.device("cuda", 0)
+    tg = [{"labels": torch.zeros(0, dtype=torch.int64), "boxes": torch.zeros(0, 4)},
+          {"labels": torch.tensor([1, 0]), "boxes": torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.3, 0.3, 0.1, 0.4]])}]
+    p = detr_amd.PackedTargets.from_host(tg, dev)
+    assert p.sizes == [0, 2] and p.offsets_host.tolist() == [0, 0, 2]
+    none = detr_amd.PackedTargets.from_host([tg[0], tg[0]], dev)
+    assert none.total == 0 and none.max_t == 0
