@@ -33,7 +33,9 @@ def build_library(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + \
+    # DETR_AMD_EXTRA_FLAGS: extra hipcc flags for instrumented one-off builds (e.g. -DDM_LAP_STAMPS)
+    extra = os.environ.get("DETR_AMD_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", LIB] + \
           [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libdetr_match.so")
+# DETR_AMD_LIB: an instrumented build of the same sources (profiling tools only)
+LIB_PATH = os.environ.get("DETR_AMD_LIB") or os.path.join(_PKG, "libdetr_match.so")
 
 ABI_VERSION = 1
 MAX_SETS_PER_LAUNCH = 16

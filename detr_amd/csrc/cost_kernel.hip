@@ -20,11 +20,28 @@
 // the two divisions of the GIoU are evaluated as reciprocal * numerator (v_rcp_f32, 1 ulp)
 // and the final sums use explicit fma -- within 1e-7 relative of the reference's
 // separately rounded operations, far inside the 1e-5 parity bar.
+#include <algorithm>
+
 #include "dm_common.h"
 
 namespace {
 
 constexpr int TCHUNK = 64;   // targets staged per pass
+#ifndef DM_TILE_ABL
+#define DM_TILE_ABL 0
+#endif
+// cache-policy bits of the tile's LDS-DMA loads: 2 = nt (the logits are read once; keeping them
+// out of the way of the cost rows being assembled in L2 measured 6 % faster)
+#ifndef DM_TILE_LDAUX
+#define DM_TILE_LDAUX 2
+#endif
+// nontemporal stores of the small-C kernel's cost rows (measured 8 % faster on the largest batches)
+#ifndef DM_SMALL_NTST
+#define DM_SMALL_NTST 1
+#endif
+#ifndef DM_TILE_NTST
+#define DM_TILE_NTST 0
+#endif
 
 struct __align__(16) TgtRec {
     float x0, y0, x1, y1;    // box_ops.py:17-21
@@ -64,6 +81,8 @@ __device__ __forceinline__ float pow_gamma(float x, float gamma)
 // complement keeps full relative accuracy where the reference's fp32 `1 - p` has lost it
 // (it stays within one rounding of p of the reference's value); exp and log are the
 // hardware v_exp_f32 / v_log_f32 (1 ulp).
+// G2: gamma == 2 is known at compile time (keeps the general powf out of the instruction stream).
+template <bool G2 = false>
 __device__ __forceinline__ float focal_cost(float x, float alpha, float gamma)
 {
     const float a = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896f);
@@ -73,8 +92,8 @@ __device__ __forceinline__ float focal_cost(float x, float alpha, float gamma)
     const float q = x >= 0.0f ? small : big;                // 1 - p
     const float nlog_q = -(__builtin_amdgcn_logf(q + 1e-8f) * 0.693147180559945f);
     const float nlog_p = -(__builtin_amdgcn_logf(p + 1e-8f) * 0.693147180559945f);
-    const float neg = ((1.0f - alpha) * pow_gamma(p, gamma)) * nlog_q;
-    const float pos = (alpha * pow_gamma(q, gamma)) * nlog_p;
+    const float neg = ((1.0f - alpha) * (G2 ? p * p : pow_gamma(p, gamma))) * nlog_q;
+    const float pos = (alpha * (G2 ? q * q : pow_gamma(q, gamma))) * nlog_p;
     return pos - neg;
 }
 
@@ -237,7 +256,11 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                 }
                 float *dst = out + (size_t)(tc + i) * qs;
                 if (QPT == 1 || wide) {
+#if DM_SMALL_NTST
+                    __builtin_nontemporal_store(r, reinterpret_cast<vecq *>(dst));
+#else
                     *reinterpret_cast<vecq *>(dst) = r;
+#endif
                 } else {
 #pragma unroll
                     for (int k = 0; k < QPT; ++k) if (q0 + k < Q) dst[k] = r[k];
@@ -248,25 +271,35 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
     }
 }
 
-// C > 4.  blockDim = 256: wavefront w of the workgroup handles targets t = w (mod 4) of the
-// 64 queries [64 * blockIdx.x, +64); all four stream the 64 x C logit tile into LDS together.
-__global__ __launch_bounds__(256) void cost_tile_kernel(const DmSetArray sets, const int C,
-                                                        const int64_t *__restrict__ labels,
-                                                        const float *__restrict__ tboxes,
-                                                        const int32_t *__restrict__ tgt_off, const DmParams prm,
-                                                        float *__restrict__ cost, int32_t *status)
+// C > 4.  blockDim = 64 * W: wavefront w of the workgroup handles targets t = w (mod W) of one
+// tile of 64 queries of one image, two targets per trip (two independent dependency chains per
+// lane); all W wavefronts stream the 64 x C logit tile into LDS together (LDS-DMA where the rows
+// allow it: no registers, every piece in flight at once).
+// One-dimensional grid, workgroup id = (set * B + image) * ntiles + tile.  (Giving all tiles of an
+// image to workgroups of one XCD, so that the 256-byte pieces of a cost row meet in one L2, measured
+// 5 % slower: it concentrates the heavy images on single XCDs.)
+// MODE: 0 softmax class cost, 1 focal with gamma == 2, 2 focal with any gamma.
+template <int W, int MODE>
+__global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets, const int nsets, const int B,
+                                                           const int C, const int64_t *__restrict__ labels,
+                                                           const float *__restrict__ tboxes,
+                                                           const int32_t *__restrict__ tgt_off, const DmParams prm,
+                                                           float *__restrict__ cost, int32_t *status, const int ntiles)
 {
+    constexpr int NT = 64 * W;
     extern __shared__ __align__(16) unsigned char smem[];
     TgtRec *tg = reinterpret_cast<TgtRec *>(smem);                                   // [TCHUNK]
-    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [4][64] softmax partials
-    float *tile = part + 256;                                                        // [64][Cs]
+    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [8][64] softmax partials
+    float *tile = part + (MODE == 0 ? 64 * 8 : 0);                                   // [64][Cs]
 
-    const DmSet &set = sets.s[blockIdx.z];
-    const int b = blockIdx.y;
+    const int unit = blockIdx.x / ntiles, tile_id = blockIdx.x - unit * ntiles;
+    if (unit >= nsets * B) return;
+    const int si = unit / B, b = unit - si * B;
+    const DmSet &set = sets.s[si];
     const int Q = set.Q;
-    const int q0 = blockIdx.x * 64;
-    if (q0 >= Q) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = tile_id * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: loop counters stay scalar
     const int q = q0 + lane;
     const bool active = q < Q;
     const int nq = min(64, Q - q0);
@@ -281,32 +314,40 @@ __global__ __launch_bounds__(256) void cost_tile_kernel(const DmSetArray sets, c
         // land on consecutive LDS banks
         const float *src = set.logits + ((size_t)b * Q + q0) * (size_t)C;
         const int n = nq * C;
+#if DM_TILE_ABL == 2
+        if (false) {
+#else
         if ((C & 1) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+#endif
             // odd C: the LDS image (row stride C) is a linear copy of the rows -> LDS-DMA, 1 KB per
-            // wave instruction, no registers, every piece in flight at once
-            for (int base = wave * 256; base < n; base += 4 * 256) {
+            // wave instruction
+            for (int base = wave * 256; base < n; base += W * 256) {
                 const int e = base + lane * 4;
                 if (e + 3 < n)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e),
-                                                     (__attribute__((address_space(3))) void *)(tile + base), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(tile + base), 16, 0, DM_TILE_LDAUX);
             }
             const int n4 = n & ~3;
             if (tid < n - n4) tile[n4 + tid] = src[n4 + tid];
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if DM_TILE_ABL == 2
+        } else if (false) {
+#else
         } else {
-            const int step_r = 256 / C, step_c = 256 % C;
+#endif
+            const int step_r = NT / C, step_c = NT % C;
             int r = tid / C, c = tid - r * C;
-            constexpr int U = 8;
-            for (int base = 0; base < n; base += 256 * U) {
-                float v[U];
+            constexpr int UL = 8;
+            for (int base = 0; base < n; base += NT * UL) {
+                float v[UL];
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int e = base + k * 256 + tid;
+                for (int k = 0; k < UL; ++k) {
+                    const int e = base + k * NT + tid;
                     v[k] = src[min(e, n - 1)];
                 }
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int e = base + k * 256 + tid;
+                for (int k = 0; k < UL; ++k) {
+                    const int e = base + k * NT + tid;
                     if (e < n) tile[r * Cs + c] = v[k];
                     c += step_c; r += step_r;
                     if (c >= C) { c -= C; ++r; }
@@ -322,20 +363,33 @@ __global__ __launch_bounds__(256) void cost_tile_kernel(const DmSetArray sets, c
 
     const float *xr = tile + lane * Cs;
     float ce_max = 0.0f, ce_den = 1.0f;
-    if (prm.cls_mode == 0) {
-        // softmax statistics of the lane's row, the class range split over the four wavefronts
+    if (MODE == 0) {
+        // softmax statistics of the lane's row: the classes form 8 residue classes (mod 8) that the
+        // wavefronts share out; the partial sums meet in a fixed tree, so the result does not
+        // depend on the number of wavefronts
         float mx = -__builtin_huge_valf();
-        for (int c = wave; c < C; c += 4) mx = fmaxf(mx, xr[c]);
+        for (int c = wave; c < C; c += W) mx = fmaxf(mx, xr[c]);
         part[wave * 64 + lane] = mx;
         __syncthreads();
-        mx = fmaxf(fmaxf(part[lane], part[64 + lane]), fmaxf(part[128 + lane], part[192 + lane]));
+        mx = part[lane];
+#pragma unroll
+        for (int w = 1; w < W; ++w) mx = fmaxf(mx, part[w * 64 + lane]);
         __syncthreads();
-        float den = 0.0f;
-        for (int c = wave; c < C; c += 4) den += expf(xr[c] - mx);
-        part[wave * 64 + lane] = den;
+        for (int r = wave; r < 8; r += W) {
+            float den = 0.0f;
+            for (int c = r; c < C; c += 8) den += expf(xr[c] - mx);
+            part[r * 64 + lane] = den;
+        }
         __syncthreads();
         ce_max = mx;
-        ce_den = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+        float dsum[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dsum[r] = part[r * 64 + lane];
+#pragma unroll
+        for (int h = 4; h >= 1; h /= 2)
+#pragma unroll
+            for (int r = 0; r < h; ++r) dsum[r] = dsum[2 * r] + dsum[2 * r + 1];
+        ce_den = dsum[0];
     }
 
     const int qs = set.q_stride;
@@ -348,13 +402,43 @@ __global__ __launch_bounds__(256) void cost_tile_kernel(const DmSetArray sets, c
             stage_targets(tg, labels, tboxes, t0 + tc, nt, C, status);
             __syncthreads();
         }
+#if DM_TILE_ABL == 1
+        if (active && prm.w_bbox == 123.0f) {
+#else
         if (active) {
-            for (int i = wave; i < nt; i += 4) {
+#endif
+            auto element = [&](int i) {
                 const TgtRec g = tg[i];
                 const float xl = xr[g.label];
-                const float cls = prm.cls_mode == 0 ? -(expf(xl - ce_max) / ce_den)
-                                                    : focal_cost(xl, prm.focal_alpha, prm.focal_gamma);
-                out[(size_t)(tc + i) * qs] = pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
+                float cls;
+                if (MODE == 0) cls = -(expf(xl - ce_max) / ce_den);
+                else cls = focal_cost<MODE == 1>(xl, prm.focal_alpha, prm.focal_gamma);
+                return pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
+            };
+            float *dst = out + (size_t)(tc + wave) * qs;
+            const size_t hop = (size_t)W * qs;
+            int i = wave;
+            for (; i + W < nt; i += 2 * W, dst += 2 * hop) {
+                const float r0 = element(i), r1 = element(i + W);
+#if DM_TILE_ABL == 3
+                if (r0 == 123.456f) { dst[0] = r0; dst[hop] = r1; }
+#elif DM_TILE_NTST
+                __builtin_nontemporal_store(r0, dst);
+                __builtin_nontemporal_store(r1, dst + hop);
+#else
+                dst[0] = r0;
+                dst[hop] = r1;
+#endif
+            }
+            if (i < nt) {
+                const float r0 = element(i);
+#if DM_TILE_ABL == 3
+                if (r0 == 123.456f) dst[0] = r0;
+#elif DM_TILE_NTST
+                __builtin_nontemporal_store(r0, dst);
+#else
+                dst[0] = r0;
+#endif
             }
         }
     }
@@ -374,6 +458,7 @@ int pick_waves(int Q, int max_waves)
 
 thread_local char g_hip_err[256] = "";
 int g_cost_tsplit = 0;   // 0: automatic; otherwise forced target split (testing aid)
+int g_tile_waves = 0;     // 0: automatic; 4 / 8: wavefronts per workgroup of the tile kernel (testing aid)
 int g_cost_qpt = 0;   // 0: automatic; 1 / 2: force the queries-per-thread variant (testing aid)
 
 }  // namespace
@@ -384,6 +469,7 @@ extern "C" const char *dm_last_hip_error(void) { return g_hip_err; }
 // the small-C cost kernel.
 extern "C" void dm_debug_cost_queries_per_thread(int qpt)
 {
+    if (qpt >= 300) { g_tile_waves = qpt - 300; return; }     // 304 / 308: wavefronts per workgroup
     if (qpt >= 200) { g_cost_tsplit = qpt - 200; return; }   // 201, 202, 204: forced target split
     g_cost_qpt = (qpt == 1 || qpt == 2) ? qpt : 0;
 }
@@ -407,10 +493,19 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     if (B > 65535 || S > 4096) return DM_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tile = C > 4;
-    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + 256 * sizeof(float) + (size_t)64 * (C | 1) * sizeof(float);
+    // tile kernel: LDS = staged targets + softmax partials (softmax variant) + the logit tile
+    const int mode = params->cls_mode == 0 ? 0 : (params->focal_gamma == 2.0f ? 1 : 2);
+    const int tile_waves = g_tile_waves == 8 ? 8 : 4;
+    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 8 * sizeof(float) : 0) +
+                            (size_t)64 * (C | 1) * sizeof(float);
     if (tile && tile_lds > 160 * 1024) return DM_E_UNSUPPORTED;
+    typedef void (*TileFn)(const DmSetArray, const int, const int, const int, const int64_t *, const float *,
+                           const int32_t *, const DmParams, float *, int32_t *, const int);
+#define DM_TILE_FN(WW) (mode == 0 ? cost_tile_kernel<WW, 0> : mode == 1 ? cost_tile_kernel<WW, 1> : cost_tile_kernel<WW, 2>)
+    const TileFn tile_fn = tile_waves == 4 ? DM_TILE_FN(4) : DM_TILE_FN(8);
+#undef DM_TILE_FN
     if (tile && tile_lds > 64 * 1024) {
-        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&cost_tile_kernel),
+        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_fn),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds),
                                "hipFuncSetAttribute(cost_tile_kernel)");
         if (rc != DM_OK) return rc;
@@ -431,9 +526,12 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
             }
             if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
                 if (tile) {
-                    dim3 grid((Q + 63) / 64, B, n);
-                    hipLaunchKernelGGL(cost_tile_kernel, grid, dim3(256), tile_lds, st, arr, C, tgt_labels, tgt_boxes,
-                                       tgt_off, *params, cost, status);
+                    const int ntiles = (Q + 63) / 64;
+                    const long long units = (long long)B * n;
+                    const long long wgs = units * ntiles;
+                    if (wgs > 0x7fffffffLL) return DM_E_UNSUPPORTED;
+                    hipLaunchKernelGGL(tile_fn, dim3((unsigned)wgs), dim3(64 * tile_waves), tile_lds, st, arr, n, B, C,
+                                       tgt_labels, tgt_boxes, tgt_off, *params, cost, status, ntiles);
                 } else {
                     // one query per thread keeps the most wavefronts in flight; the two-query
                     // variant (8-byte stores) measured no faster at any size and stays a testing aid

@@ -132,7 +132,9 @@ int dm_profile_read(float *cost_ms, float *lap_ms);
  * 1: list-order kernel only, 2: workgroup-per-problem kernel, 3: wavefront-per-problem kernel. */
 void dm_debug_force_generic_lap(int mode);
 
-/* Testing aid: 0 automatic, 1 / 2 force one / two queries per thread in the C <= 4 cost kernel. */
+/* Testing aid: 0 automatic, 1 / 2 force one / two queries per thread in the C <= 4 cost kernel;
+ * 201 / 202 / 204 force its target split (200 automatic); 304 / 308 set the wavefronts per
+ * workgroup of the C > 4 cost kernel (300 automatic). */
 void dm_debug_cost_queries_per_thread(int qpt);
 
 #ifdef __cplusplus

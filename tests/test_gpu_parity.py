@@ -234,6 +234,26 @@ def test_workload_cfg4_full_size_properties():
     _check_workload("cfg4", lap_sample=24)
 
 
+@pytest.mark.parametrize("name", ["focal_c91_q100", "ce_c92_q100", "focal_c4_gamma15", "focal_c2_q300"])
+def test_cost_kernel_shape_knobs_do_not_change_the_cost(name):
+    """Wavefronts per workgroup (C > 4 kernel), queries per thread and target split (C <= 4 kernel)
+    are launch shapes only: every one of them yields bit-identical cost blocks."""
+    import detr_amd
+
+    g = golden_io.load(name)
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = _matcher(**g.matcher_kwargs())
+    base = [blk.clone() for blk in matcher.cost_blocks(outputs, targets)]
+    try:
+        for code in (304, 308, 2, 1, 201, 202, 204):
+            detr_amd.lib.dm_debug_cost_queries_per_thread(code)
+            for a, b in zip(base, matcher.cost_blocks(outputs, targets)):
+                assert torch.equal(a, b), code
+    finally:
+        for code in (300, 200, 0):
+            detr_amd.lib.dm_debug_cost_queries_per_thread(code)
+
+
 def test_image_order_invariance():
     import detr_amd
     from detr_amd import synth

@@ -27,11 +27,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--which", default="cost,lap")
-    ap.add_argument("--qpt", type=int, default=0)
+    ap.add_argument("--qpt", default="0", help="comma-separated codes for dm_debug_cost_queries_per_thread")
     ap.add_argument("--lapmode", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    lib.dm_debug_cost_queries_per_thread(args.qpt)
+    for code in args.qpt.split(","):
+        lib.dm_debug_cost_queries_per_thread(int(code))
     lib.dm_debug_force_generic_lap(args.lapmode)
     wl, sets, targets = synth.make_workload(args.workload, device=dev, batch=args.batch)
     packed = PackedTargets(targets, dev)
@@ -85,6 +86,12 @@ def main():
     if "lap" in args.which:
         us = timeit(run_lap, args.iters)
         print(f"lap : {us:8.2f} us/launch  {S * B / us:8.2f} problems/us  (P={S * B}, max T={packed.max_t})")
+    if "both" in args.which:
+        def run_both():
+            run_cost()
+            run_lap()
+        us = timeit(run_both, args.iters)
+        print(f"both: {us:8.2f} us per cost+lap pair")
     print("status", int(out[-1].item()))
 
 
