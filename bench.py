@@ -32,6 +32,22 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+
+
+def measured_traffic(kernel, workload):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 counter passes
+    (FETCH_SIZE doubled as gfx950 needs + WRITE_SIZE, separate --pmc runs of this script; made
+    by tools/pmc_traffic.py).  None when the file does not cover this kernel at this workload."""
+    try:
+        with open(PMC_TRAFFIC) as f:
+            table = json.load(f)
+    except OSError:
+        return None
+    entry = table.get(kernel)
+    if not entry or entry.get("workload") != workload:
+        return None
+    return entry["traffic_bytes"]
 
 
 def cost_kernel_bytes(set_queries, n_logits, sizes):
@@ -113,6 +129,7 @@ def stress_roofline(device, launches=20):
     achieved = algo / (ms * 1e-3) / 1e9
     return {"workload": "cfg4 cost kernel only: B=256, Q=900, C=91, heavy-tail T, 6 sets", "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": measured_traffic("cost_tile_kernel", "cfg4"),
             "kernel": "cost_tile_kernel", "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms}
 
 
@@ -200,6 +217,7 @@ def main():
         cost_ms_avg = cost_ms_sum / args.steps
         lap_ms_avg = lap_ms_sum / args.steps
         algo_bytes = cost_kernel_bytes(wl.set_queries, wl.n_logits, sizes)
+        cost_kernel_name = "cost_small_kernel" if wl.n_logits <= 4 else "cost_tile_kernel"
         achieved = algo_bytes / (cost_ms_avg * 1e-3) / 1e9
         record = {
             "metric": "matched images/sec (Q=600, ~16 GT/img, 6 aux layers); cost-kernel HBM GB/s",
@@ -219,8 +237,9 @@ def main():
                                    f"{len(wl.set_queries) * B} assignment problems per step per GPU",
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "cost_kernel", "algorithmic_bytes_per_step": algo_bytes,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(cost_kernel_name, wl.name) if B == wl.batch else None,
+                         "kernel": cost_kernel_name, "algorithmic_bytes_per_step": algo_bytes,
                          "ms_per_step_hip_events": cost_ms_avg},
             "lap": {"kernel": "lap_block_kernel / lap_wave_kernel", "ms_per_step_hip_events": lap_ms_avg,
                     "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
