@@ -60,7 +60,10 @@ def cost_kernel_bytes(set_queries, n_logits, sizes):
     return total
 
 
-def cpu_baseline(wl, sets, targets, budget_s=20.0):
+def cpu_baseline(wl, sets, targets, min_s=10.0, budget_s=20.0):
+    """The reference's CPU formulation on this host: whole steps of the same workload, repeated
+    until `min_s` seconds of CPU work are done (at most `budget_s`), at torch's default thread
+    count; then a bounded single-thread sample of the same calls."""
     from oracle import torch_pipeline
 
     cpu_sets = [{k: v.cpu() for k, v in s.items()} for s in sets]
@@ -69,19 +72,31 @@ def cpu_baseline(wl, sets, targets, budget_s=20.0):
     # one untimed call to warm the allocator / thread pool
     torch_pipeline.match(cpu_sets[0]["pred_logits"][:2], cpu_sets[0]["pred_boxes"][:2], cpu_targets[:2],
                          **wl.matcher_kwargs)
-    done, t0 = 0, time.perf_counter()
-    for s in cpu_sets:
-        torch_pipeline.match(s["pred_logits"], s["pred_boxes"], cpu_targets, **wl.matcher_kwargs)
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    elapsed = time.perf_counter() - t0
+
+    def run(min_time, max_time):
+        done, t0 = 0, time.perf_counter()
+        while True:
+            s = cpu_sets[done % len(cpu_sets)]
+            torch_pipeline.match(s["pred_logits"], s["pred_boxes"], cpu_targets, **wl.matcher_kwargs)
+            done += 1
+            t = time.perf_counter() - t0
+            if t > max_time or (t > min_time and done % len(cpu_sets) == 0):
+                return done, t
+
+    done, elapsed = run(min_s, budget_s)
     step_s = elapsed * len(cpu_sets) / done
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        done1, elapsed1 = run(0.0, 6.0)
+    finally:
+        torch.set_num_threads(threads)
     return {
-        "value": B / step_s, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{done} of {len(cpu_sets)} matcher calls of one {wl.name} step (B={B}) in {elapsed:.1f} s, "
-                  f"scaled to the full step; torch {torch.__version__} CPU ops on the whole-batch "
-                  f"[B*Q, sum T] matrix + scipy per image",
+        "value": B / step_s, "unit": "images/s", "cores": threads, "kind": "port",
+        "sample": f"{done} matcher calls ({done / len(cpu_sets):.2f} steps of {wl.name}, B={B}) in {elapsed:.1f} s; "
+                  f"torch {torch.__version__} CPU ops on the whole-batch [B*Q, sum T] matrix + scipy per image",
+        "single_thread_value": B / (elapsed1 * len(cpu_sets) / done1),
+        "single_thread_sample": f"{done1} matcher calls in {elapsed1:.1f} s with torch.set_num_threads(1)",
     }
 
 
@@ -131,6 +146,26 @@ def stress_roofline(device, launches=20):
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic("cost_tile_kernel", "cfg4"),
             "kernel": "cost_tile_kernel", "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms}
+
+
+def flat_path(matcher, sets, targets, device, steps):
+    """The same step through the opt-in interface that keeps everything on the device: targets
+    packed once per batch (as a collate function would), `match_flat` (flat index tensors, no
+    device-to-host copy, no per-image views).  Not the headline value: a different contract."""
+    import detr_amd
+
+    packed = detr_amd.PackedTargets(targets, device)
+    for _ in range(10):
+        matcher.match_flat(sets, packed)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        matcher.match_flat(sets, packed)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    matcher.check_status()
+    return {"value": len(targets) * steps / elapsed, "unit": "images/s", "ms_per_step": 1e3 * elapsed / steps,
+            "what": "match_flat on pre-packed targets: device-resident flat indices, one sync after all steps"}
 
 
 def main():
@@ -244,6 +279,8 @@ def main():
             "lap": {"kernel": "lap_block_kernel / lap_wave_kernel", "ms_per_step_hip_events": lap_ms_avg,
                     "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
         }
+        if world == 1:
+            record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
         if world == 1 and not args.no_stress:
             record["roofline_stress"] = stress_roofline(device)
         if world == 1 and not args.no_cpu_baseline:

@@ -351,20 +351,20 @@ class HungarianMatcher(torch.nn.Module):
             return []
         out, queries, _, _ = self._launch(outputs_list, packed)
         M, sizes = packed.total, packed.sizes
+        both = out[:2 * S * M].view(2, S, M)
+        batch_idx, base = packed.batch_index, packed.target_base
+        flat_all = both[1] + base if M > 0 else both[1]       # one launch for every set
         result = []
         for s, q in enumerate(queries):
-            src = out[s * M:(s + 1) * M]
-            tgt = out[S * M + s * M:S * M + (s + 1) * M]
+            src, tgt, flat = both[0, s], both[1, s], flat_all[s]
             if M == 0 or q >= packed.max_t:
-                batch_idx, base = packed.batch_index, packed.target_base
-            else:
-                # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
-                keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
-                                       for o, t in zip(packed.offsets_host[:-1], sizes)] + [np.zeros(0, np.int64)])
-                keep_dev = torch.from_numpy(keep).to(device)
-                src, tgt = src[keep_dev], tgt[keep_dev]
-                batch_idx, base = packed.batch_index[keep_dev], packed.target_base[keep_dev]
-            result.append(FlatMatches(batch_idx, src, tgt, tgt + base, packed, q))
+                result.append(FlatMatches(batch_idx, src, tgt, flat, packed, q))
+                continue
+            # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
+            keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
+                                   for o, t in zip(packed.offsets_host[:-1], sizes)] + [np.zeros(0, np.int64)])
+            keep_dev = torch.from_numpy(keep).to(device)
+            result.append(FlatMatches(batch_idx[keep_dev], src[keep_dev], tgt[keep_dev], flat[keep_dev], packed, q))
         return result
 
     def check_status(self):

@@ -41,3 +41,23 @@ for _ in range(N):
     m.match_many(sets, targets)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+t0 = time.perf_counter()
+for _ in range(N):
+    m.match_flat(sets, packed)
+torch.cuda.synchronize()
+print("us/step pre-packed, match_flat", (time.perf_counter() - t0) / N * 1e6)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    m.match_flat(sets, packed)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("match_flat host us/call", (t1 - t0) / N * 1e6, " drain us", (t2 - t1) * 1e6)
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(N):
+    m.match_flat(sets, packed)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)
