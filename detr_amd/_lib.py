@@ -28,6 +28,11 @@ class DmSet(ctypes.Structure):
                 ("Q", ctypes.c_int32), ("q_stride", ctypes.c_int32)]
 
 
+class DmIndexSet(ctypes.Structure):
+    _fields_ = [("pred_boxes", ctypes.c_void_p), ("grad_boxes", ctypes.c_void_p), ("target_cls", ctypes.c_void_p),
+                ("out_off", ctypes.c_int64), ("Q", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class DmParams(ctypes.Structure):
     _fields_ = [("cls_mode", ctypes.c_int32), ("w_class", ctypes.c_float), ("w_bbox", ctypes.c_float),
                 ("w_giou", ctypes.c_float), ("focal_alpha", ctypes.c_float), ("focal_gamma", ctypes.c_float)]
@@ -36,7 +41,8 @@ class DmParams(ctypes.Structure):
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_profile_enable", "dm_profile_read",
-           "dm_debug_force_generic_lap", "dm_debug_cost_queries_per_thread"]
+           "dm_debug_force_generic_lap", "dm_debug_cost_queries_per_thread",
+           "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64"]
 
 
 def _load():
@@ -61,6 +67,13 @@ def _load():
     lib.dm_lap_f32.argtypes = [setp, i32, i32, vp, vp, vp, i32, i64p, i64p, vp, vp]
     lib.dm_match_f32.restype = ctypes.c_int
     lib.dm_match_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, prmp, vp, i64p, i64p, vp, vp]
+    isetp = ctypes.POINTER(DmIndexSet)
+    lib.dm_pair_loss_f32.restype = ctypes.c_int
+    lib.dm_pair_loss_f32.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, vp, vp, vp]
+    lib.dm_pair_loss_backward_f32.restype = ctypes.c_int
+    lib.dm_pair_loss_backward_f32.argtypes = [isetp, i32, i32, i32, vp, i64p, i64p, vp, vp, vp]
+    lib.dm_target_classes_i64.restype = ctypes.c_int
+    lib.dm_target_classes_i64.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, ctypes.c_int64, vp]
     lib.dm_debug_force_generic_lap.restype = None
     lib.dm_debug_force_generic_lap.argtypes = [ctypes.c_int]
     lib.dm_debug_cost_queries_per_thread.restype = None

@@ -150,9 +150,12 @@ class FlatMatches:
 
     Nothing here synchronises with the host."""
 
-    def __init__(self, batch_idx, src_idx, tgt_idx, tgt_flat, packed, queries):
+    def __init__(self, batch_idx, src_idx, tgt_idx, tgt_flat, packed, queries, raw=None, set_index=0):
         self.batch_idx, self.src_idx, self.tgt_idx, self.tgt_flat = batch_idx, src_idx, tgt_idx, tgt_flat
         self.packed, self.queries = packed, queries
+        # (index buffer [src (S*M) | tgt (S*M) | status], S) of the launch this set came from and the
+        # set's position in it: what detr_amd.losses hands to the fused consumer kernels
+        self.raw, self.set_index = raw, set_index
 
     @property
     def num_matched(self) -> int:
@@ -358,13 +361,14 @@ class HungarianMatcher(torch.nn.Module):
         for s, q in enumerate(queries):
             src, tgt, flat = both[0, s], both[1, s], flat_all[s]
             if M == 0 or q >= packed.max_t:
-                result.append(FlatMatches(batch_idx, src, tgt, flat, packed, q))
+                result.append(FlatMatches(batch_idx, src, tgt, flat, packed, q, (out, S), s))
                 continue
             # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
             keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
                                    for o, t in zip(packed.offsets_host[:-1], sizes)] + [np.zeros(0, np.int64)])
             keep_dev = torch.from_numpy(keep).to(device)
-            result.append(FlatMatches(batch_idx[keep_dev], src[keep_dev], tgt[keep_dev], flat[keep_dev], packed, q))
+            result.append(FlatMatches(batch_idx[keep_dev], src[keep_dev], tgt[keep_dev], flat[keep_dev], packed, q,
+                                      (out, S), s))
         return result
 
     def check_status(self):

@@ -119,6 +119,51 @@ int dm_match_f32(const DmSet *sets, int S, int B, int C,
                  float *cost, int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
 
 /*
+ * ---- Consumers of the indices (the criterion's first steps after the matcher) ----------------
+ * One output set as these entry points see it.  src / tgt are the buffers dm_lap_f32 wrote
+ * (same layout, same out_off); everything stays on the device.
+ */
+typedef struct DmIndexSet {
+    const float *pred_boxes; /* device [B, Q, 4] cxcywh (dm_pair_loss_f32) or NULL */
+    float *grad_boxes;       /* device [B, Q, 4], every element written (dm_pair_loss_backward_f32) or NULL */
+    int64_t *target_cls;     /* device [B, Q], every element written (dm_target_classes_i64) or NULL */
+    int64_t out_off;         /* element offset of the set's region in src / tgt */
+    int32_t Q;               /* queries per image */
+    int32_t reserved;
+} DmIndexSet;
+
+/*
+ * L1 and GIoU loss sums of the matched pairs of every set: replaces the gathers, the [N, N]
+ * generalized_box_iou + diag and the reductions of calc_box_loss
+ * (/root/reference/models/detr/loss.py:97-112; the caller divides by num_boxes, :106,112).
+ *   sums       device float[S][2]: sum |pred - target| and sum (1 - giou) of set s
+ *   pair_grad  device float[S][M][8] or NULL: per packed slot, d l1 / d pred (4) and
+ *              d (1 - giou) / d pred (4) in cxcywh; zero for slots without a pair
+ * M = tgt_off[B] (host-known).  Fixed-order reductions: bitwise reproducible.
+ */
+int dm_pair_loss_f32(const DmIndexSet *sets, int S, int B, int M, const float *tgt_boxes,
+                     const int32_t *tgt_off, const int64_t *src, const int64_t *tgt,
+                     float *sums, float *pair_grad, void *stream);
+
+/*
+ * Backward of dm_pair_loss_f32: grad_boxes[b][q] = grad_sums[s][0] * d l1 + grad_sums[s][1] *
+ * d (1 - giou) for matched queries, 0 elsewhere (what autograd produces for loss.py:102-112).
+ *   grad_sums  device float[S][2]
+ * Limit: Q <= 40960 (DM_E_UNSUPPORTED beyond).
+ */
+int dm_pair_loss_backward_f32(const DmIndexSet *sets, int S, int B, int M, const int32_t *tgt_off,
+                              const int64_t *src, const int64_t *tgt, const float *pair_grad,
+                              const float *grad_sums, void *stream);
+
+/*
+ * Dense class map of every set: target_cls[b][q] = label of the target matched to query q, else
+ * no_object (/root/reference/models/detr/loss.py:121-125).  Limit: Q <= 40960.
+ */
+int dm_target_classes_i64(const DmIndexSet *sets, int S, int B, int M, const int64_t *tgt_labels,
+                          const int32_t *tgt_off, const int64_t *src, const int64_t *tgt,
+                          int64_t no_object, void *stream);
+
+/*
  * Measurement aids (no counterpart in the reference).  With profiling enabled,
  * dm_match_f32 records HIP events on its stream before the cost kernels, between the cost
  * and the assignment kernels, and after the assignment kernels; dm_profile_read returns the
