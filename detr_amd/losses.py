@@ -2,6 +2,7 @@
 (/root/reference/models/detr/loss.py:97-125 and its twins in the other criteria):
 
     matched_box_losses(outputs_list, flats)   -> [(l1_loss, giou_loss)] per output set, differentiable
+    matched_box_loss_total(outputs_list, flats, l1_weight, giou_weight) -> their weighted sum, one scalar
     target_class_maps(flats, no_object)       -> [dense [B, Q] int64 class map] per output set
 
 Both take the `FlatMatches` of ONE `HungarianMatcher.match_flat` call and handle all of its output
@@ -90,6 +91,17 @@ def matched_box_losses(outputs_list, flats: Sequence[FlatMatches]) -> List[Tuple
         n = float(max(f.num_matched, 1))
         result.append((sums[i, 0] / n, sums[i, 1] / n))
     return result
+
+
+def matched_box_loss_total(outputs_list, flats: Sequence[FlatMatches], l1_weight: float = 1.0,
+                           giou_weight: float = 1.0) -> torch.Tensor:
+    """sum over the output sets of `l1_weight * l1_loss + giou_weight * giou_loss` -- the box part of
+    the reference's total loss (loss.py:135-160 adds the per-layer losses with these weights) --
+    as one scalar with two autograd nodes instead of a dozen per set."""
+    sums = _PairLossSums.apply(list(flats), *[o["pred_boxes"] for o in outputs_list])
+    scale = torch.tensor([[l1_weight / max(f.num_matched, 1), giou_weight / max(f.num_matched, 1)] for f in flats],
+                         dtype=torch.float32).to(sums.device, non_blocking=True)
+    return (sums * scale).sum()
 
 
 @torch.no_grad()

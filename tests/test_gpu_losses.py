@@ -101,6 +101,14 @@ def test_all_sets_of_a_step_against_torch_autograd(name, batch):
         assert _close(got[s][0].item(), l1.item()) and _close(got[s][1].item(), giou.item())
         ref_grad, = torch.autograd.grad(5.0 * l1 + 2.0 * giou, ref_boxes)
         torch.testing.assert_close(grads[s], ref_grad, rtol=1e-5, atol=1e-6)
+    # the weighted total in one scalar gives the same value and gradients
+    for o in sets:
+        o["pred_boxes"].grad = None
+    one = losses.matched_box_loss_total(sets, flats, 5.0, 2.0)
+    assert _close(one.item(), total.item())
+    one.backward()
+    for s, o in enumerate(sets):
+        torch.testing.assert_close(o["pred_boxes"].grad, grads[s], rtol=1e-6, atol=1e-7)
     # class maps of all sets in one launch == per-set torch scatter
     no_object = wl.n_logits - 1
     maps = losses.target_class_maps(flats, no_object)
