@@ -42,7 +42,8 @@ class DmParams(ctypes.Structure):
 EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_profile_enable", "dm_profile_read",
            "dm_debug_force_generic_lap", "dm_debug_cost_queries_per_thread",
-           "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64"]
+           "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
+           "dm_atss_f32", "dm_frcnn_f32"]
 
 
 def _load():
@@ -74,6 +75,10 @@ def _load():
     lib.dm_pair_loss_backward_f32.argtypes = [isetp, i32, i32, i32, vp, i64p, i64p, vp, vp, vp]
     lib.dm_target_classes_i64.restype = ctypes.c_int
     lib.dm_target_classes_i64.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, ctypes.c_int64, vp]
+    lib.dm_atss_f32.restype = ctypes.c_int
+    lib.dm_atss_f32.argtypes = [isetp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.dm_frcnn_f32.restype = ctypes.c_int
+    lib.dm_frcnn_f32.argtypes = [isetp, i32, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp, vp]
     lib.dm_debug_force_generic_lap.restype = None
     lib.dm_debug_force_generic_lap.argtypes = [ctypes.c_int]
     lib.dm_debug_cost_queries_per_thread.restype = None

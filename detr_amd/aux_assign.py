@@ -1,0 +1,167 @@
+"""Co-DETR auxiliary label assigners on the GPU: drop-ins for `ATSS` and `FasterRCNN` of the
+reference (/root/reference/models/co_detr/auxiliary_head.py:17-60, 63-96).
+
+Same constructors, same call `head(outputs, targets)`, same return values (CPU int64 index
+tensors per image).  `assign_many(list_of_outputs, targets)` handles all output sets of a step
+(one per decoder layer, co_detr/loss.py:225-237) with one launch per kernel and one
+device-to-host copy.  Two things the reference leaves to implementation detail are fixed here:
+ATSS candidates at exactly equal centre distance are ordered by prediction index, and the
+Faster-RCNN positives of one target are listed by ascending prediction index.
+There is no CPU fallback.
+"""
+import ctypes
+from typing import Dict, List, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DmIndexSet, lib
+from .matcher import PackedTargets
+
+Pairs = List[Tuple[torch.Tensor, torch.Tensor]]
+
+
+def _prepare(outputs_list, targets):
+    if not outputs_list:
+        raise ValueError("no output sets")
+    device = outputs_list[0]["pred_boxes"].device
+    if device.type != "cuda":
+        raise RuntimeError("detr_amd auxiliary assigners run on the GPU only (got tensors on %s)" % device)
+    if isinstance(targets, PackedTargets):
+        packed = targets
+    else:
+        # the reference moves the target boxes to the predictions' device itself (auxiliary_head.py:31)
+        if any(t["boxes"].device != device for t in targets):
+            packed = PackedTargets.from_host([{k: v.cpu() for k, v in t.items()} for t in targets], device)
+        else:
+            packed = PackedTargets(targets, device)
+    sets = (DmIndexSet * len(outputs_list))()
+    keep = []
+    for i, out in enumerate(outputs_list):
+        boxes = out["pred_boxes"]
+        if boxes.dim() != 3 or boxes.shape[-1] != 4 or boxes.shape[0] != packed.batch:
+            raise ValueError("pred_boxes must be [B, Q, 4] with B = len(targets)")
+        if boxes.dtype != torch.float32:
+            raise RuntimeError(f"pred_boxes must be float32, got {boxes.dtype}")
+        boxes = boxes.detach().contiguous()
+        if boxes.data_ptr() % 16:
+            boxes = boxes.clone()
+        keep.append(boxes)
+        sets[i].pred_boxes, sets[i].Q = boxes.data_ptr(), int(boxes.shape[1])
+    return device, packed, sets, keep
+
+
+def _to_host(dev: torch.Tensor) -> np.ndarray:
+    host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+    host.copy_(dev, non_blocking=True)
+    torch.cuda.current_stream(dev.device).synchronize()
+    return host.numpy()
+
+
+class ATSS(torch.nn.Module):
+    """Adaptive training sample selection with single-scale outputs (auxiliary_head.py:17-60)."""
+
+    def __init__(self, k):
+        super().__init__()
+        self.k = k
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict[str, torch.Tensor], targets) -> Pairs:
+        return self.assign_many([outputs], targets)[0]
+
+    @torch.no_grad()
+    def assign_many(self, outputs_list: Sequence[Dict[str, torch.Tensor]],
+                    targets: Union[PackedTargets, Sequence[Dict[str, torch.Tensor]]]) -> List[Pairs]:
+        device, packed, sets, keep = _prepare(outputs_list, targets)
+        S, B, M, k = len(outputs_list), packed.batch, packed.total, int(self.k)
+        empty = torch.zeros(0, dtype=torch.int64)
+        if M == 0:
+            return [[(empty, empty) for _ in range(B)] for _ in range(S)]
+        if any(k > b.shape[1] for b in keep):
+            raise RuntimeError("selected index k out of range")      # what torch.topk raises (:38)
+        # one int64 buffer: [candidates int32 S*M*k (padded to 8 bytes) | positive masks u64 S*M]
+        n_cand = (S * M * k + 1) // 2
+        buf = torch.empty(n_cand + S * M, dtype=torch.int64, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.dm_atss_f32(sets, S, B, M, k, packed.boxes.data_ptr(), packed.offsets_ptr, buf.data_ptr(),
+                                 buf.data_ptr() + 8 * n_cand, stream)
+        _lib.check(rc, "dm_atss_f32")
+        host = _to_host(buf)
+        cand = host[:n_cand].view(np.int32)[:S * M * k].reshape(S, M, k)
+        mask = host[n_cand:].view(np.uint64).reshape(S, M)
+        bits = ((mask[:, :, None] >> np.arange(k, dtype=np.uint64)) & np.uint64(1)).astype(bool)     # [S, M, k]
+        off = packed.offsets_host
+        local = np.arange(M, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), packed.sizes)
+        result = []
+        for s in range(S):
+            per_image = []
+            for b in range(B):
+                lo, hi = int(off[b]), int(off[b + 1])
+                sel = bits[s, lo:hi]
+                src = torch.from_numpy(cand[s, lo:hi][sel].astype(np.int64))
+                tgt = torch.from_numpy(np.broadcast_to(local[lo:hi, None], sel.shape)[sel].copy())
+                per_image.append((src, tgt))
+            result.append(per_image)
+        return result
+
+
+class FasterRCNN(torch.nn.Module):
+    """IoU-threshold assignment (auxiliary_head.py:63-96): returns (pos_indices, neg_indices)."""
+
+    def __init__(self, pos_threshold=0.7, neg_threshold=0.3):
+        super().__init__()
+        self.pos_threshold = pos_threshold
+        self.neg_threshold = neg_threshold
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict[str, torch.Tensor], targets):
+        return self.assign_many([outputs], targets)[0]
+
+    @torch.no_grad()
+    def assign_many(self, outputs_list, targets):
+        device, packed, sets, keep = _prepare(outputs_list, targets)
+        S, B, M = len(outputs_list), packed.batch, packed.total
+        queries = [int(b.shape[1]) for b in keep]
+        W = (max(queries) + 63) // 64
+        if B == 0:
+            return [([], []) for _ in range(S)]
+        # one int64 buffer: [pos_bits u64 S*M*W | neg_bits u64 S*B*W | best int32 S*M]
+        n_pos, n_neg = S * M * W, S * B * W
+        buf = torch.empty(n_pos + n_neg + (S * M + 1) // 2, dtype=torch.int64, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.dm_frcnn_f32(sets, S, B, M, W, float(self.pos_threshold), float(self.neg_threshold),
+                                  packed.boxes.data_ptr(), packed.offsets_ptr, buf.data_ptr(),
+                                  buf.data_ptr() + 8 * (n_pos + n_neg), buf.data_ptr() + 8 * n_pos, stream)
+        _lib.check(rc, "dm_frcnn_f32")
+        host = _to_host(buf)
+        pos = np.unpackbits(host[:n_pos].view(np.uint8), bitorder="little").reshape(S, M, W * 64).astype(bool)
+        neg = np.unpackbits(host[n_pos:n_pos + n_neg].view(np.uint8), bitorder="little").reshape(S, B, W * 64)
+        best = host[n_pos + n_neg:].view(np.int32)[:S * M].reshape(S, M)
+        off = packed.offsets_host
+        result = []
+        for s in range(S):
+            Q = queries[s]
+            if M:
+                pos[s, np.arange(M), best[s]] = True          # the best prediction of every target (:90)
+            pos_indices, neg_indices = [], []
+            for b in range(B):
+                lo, hi = int(off[b]), int(off[b + 1])
+                t_local, q = np.nonzero(pos[s, lo:hi, :Q])      # target-major, predictions ascending
+                pos_indices.append((torch.from_numpy(q.astype(np.int64)), torch.from_numpy(t_local.astype(np.int64))))
+                neg_indices.append(torch.from_numpy(np.nonzero(neg[s, b, :Q])[0].astype(np.int64)))
+            result.append((pos_indices, neg_indices))
+        return result
+
+
+def get_aux_heads(args):
+    """As the reference's factory (auxiliary_head.py:7-15)."""
+    heads = {}
+    for key in args.aux_heads:
+        if key == "atss":
+            heads[key] = ATSS(args.atss_k)
+        if key == "faster_rcnn":
+            heads[key] = FasterRCNN()
+    return heads

@@ -164,6 +164,35 @@ int dm_target_classes_i64(const DmIndexSet *sets, int S, int B, int M, const int
                           int64_t no_object, void *stream);
 
 /*
+ * ---- Co-DETR auxiliary assigners ---------------------------------------------------------------
+ * Replace ATSS.forward and FasterRCNN.forward of
+ * /root/reference/models/co_detr/auxiliary_head.py:22-60 and 69-96 for all output sets of a step
+ * (sets[s].pred_boxes and Q are used).  They fill fixed-size tables; the caller turns them into
+ * the reference's variable-length index lists.
+ *
+ * dm_atss_f32: for target slot t of set s
+ *   cand[(s*M + t)*k + j]   the j-th closest prediction of the target's image by Euclidean distance
+ *                           of the box centres (equal distances: lower index first)
+ *   pos_mask[s*M + t]       bit j set: candidate j is a positive (IoU >= mean + unbiased std of the
+ *                           k IoUs, and its centre lies inside the target box)
+ * 1 <= k <= 64 (DM_E_UNSUPPORTED beyond); k > Q is DM_E_INVALID_ARG (the reference's topk raises).
+ */
+int dm_atss_f32(const DmIndexSet *sets, int S, int B, int M, int k, const float *tgt_boxes,
+                const int32_t *tgt_off, int32_t *cand, uint64_t *pos_mask, void *stream);
+
+/*
+ * dm_frcnn_f32: W = words per row of the bit tables, >= ceil(Q/64) of every set.
+ *   pos_bits[(s*M + t)*W + w]  bit i: IoU(target t, prediction 64w+i) > pos_threshold
+ *   best[s*M + t]              the prediction with the largest IoU for target t (first among equals);
+ *                              the reference adds it to the target's positives
+ *   neg_bits[(s*B + b)*W + w]  bit i: prediction 64w+i of image b has IoU < neg_threshold with every
+ *                              target of the image (all predictions when the image has no target)
+ */
+int dm_frcnn_f32(const DmIndexSet *sets, int S, int B, int M, int W, float pos_threshold,
+                 float neg_threshold, const float *tgt_boxes, const int32_t *tgt_off,
+                 uint64_t *pos_bits, int32_t *best, uint64_t *neg_bits, void *stream);
+
+/*
  * Measurement aids (no counterpart in the reference).  With profiling enabled,
  * dm_match_f32 records HIP events on its stream before the cost kernels, between the cost
  * and the assignment kernels, and after the assignment kernels; dm_profile_read returns the
