@@ -52,6 +52,14 @@ def _prepare(outputs_list, targets):
     return device, packed, sets, keep
 
 
+def _split_per_image(src, tgt, s_idx, t_idx, packed, S) -> List[Pairs]:
+    """(src, tgt) pairs sorted by (set, target slot) -> list over sets of lists over images of tuples."""
+    B = packed.batch
+    counts = np.bincount(s_idx * B + packed.image_index[t_idx], minlength=S * B).tolist()
+    pairs = list(zip(src.split(counts), tgt.split(counts)))
+    return [pairs[s * B:(s + 1) * B] for s in range(S)]
+
+
 def _to_host(dev: torch.Tensor) -> np.ndarray:
     host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
     host.copy_(dev, non_blocking=True)
@@ -92,19 +100,10 @@ class ATSS(torch.nn.Module):
         cand = host[:n_cand].view(np.int32)[:S * M * k].reshape(S, M, k)
         mask = host[n_cand:].view(np.uint64).reshape(S, M)
         bits = ((mask[:, :, None] >> np.arange(k, dtype=np.uint64)) & np.uint64(1)).astype(bool)     # [S, M, k]
-        off = packed.offsets_host
-        local = np.arange(M, dtype=np.int64) - np.repeat(off[:-1].astype(np.int64), packed.sizes)
-        result = []
-        for s in range(S):
-            per_image = []
-            for b in range(B):
-                lo, hi = int(off[b]), int(off[b + 1])
-                sel = bits[s, lo:hi]
-                src = torch.from_numpy(cand[s, lo:hi][sel].astype(np.int64))
-                tgt = torch.from_numpy(np.broadcast_to(local[lo:hi, None], sel.shape)[sel].copy())
-                per_image.append((src, tgt))
-            result.append(per_image)
-        return result
+        s_idx, t_idx, j_idx = np.nonzero(bits)           # set-major, then target, then candidate rank
+        src = torch.from_numpy(cand[s_idx, t_idx, j_idx].astype(np.int64))
+        tgt = torch.from_numpy(packed.local_index[t_idx])
+        return _split_per_image(src, tgt, s_idx, t_idx, packed, S)
 
 
 class FasterRCNN(torch.nn.Module):
@@ -137,22 +136,25 @@ class FasterRCNN(torch.nn.Module):
                                   buf.data_ptr() + 8 * (n_pos + n_neg), buf.data_ptr() + 8 * n_pos, stream)
         _lib.check(rc, "dm_frcnn_f32")
         host = _to_host(buf)
-        pos = np.unpackbits(host[:n_pos].view(np.uint8), bitorder="little").reshape(S, M, W * 64).astype(bool)
+        words = host[:n_pos].view(np.uint64).reshape(S, M, W)
         neg = np.unpackbits(host[n_pos:n_pos + n_neg].view(np.uint8), bitorder="little").reshape(S, B, W * 64)
         best = host[n_pos + n_neg:].view(np.int32)[:S * M].reshape(S, M)
-        off = packed.offsets_host
+        # positives are sparse: expand only the non-zero words, add the best prediction of every
+        # target (:90), then sort by (set, target, prediction) and drop the duplicates
+        s_i, t_i, w_i = np.nonzero(words)
+        r, bit = np.nonzero((words[s_i, t_i, w_i][:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1))
+        slot = np.concatenate([s_i[r] * M + t_i[r], np.arange(S * M, dtype=np.int64)])
+        q = np.concatenate([w_i[r] * 64 + bit, best.reshape(-1).astype(np.int64)])
+        key = np.unique(slot * (W * 64) + q)
+        slot, q = key // (W * 64), key % (W * 64)
+        s_idx, t_idx = slot // max(M, 1), slot % max(M, 1)
+        pos = _split_per_image(torch.from_numpy(q), torch.from_numpy(packed.local_index[t_idx]), s_idx, t_idx,
+                               packed, S)
         result = []
         for s in range(S):
             Q = queries[s]
-            if M:
-                pos[s, np.arange(M), best[s]] = True          # the best prediction of every target (:90)
-            pos_indices, neg_indices = [], []
-            for b in range(B):
-                lo, hi = int(off[b]), int(off[b + 1])
-                t_local, q = np.nonzero(pos[s, lo:hi, :Q])      # target-major, predictions ascending
-                pos_indices.append((torch.from_numpy(q.astype(np.int64)), torch.from_numpy(t_local.astype(np.int64))))
-                neg_indices.append(torch.from_numpy(np.nonzero(neg[s, b, :Q])[0].astype(np.int64)))
-            result.append((pos_indices, neg_indices))
+            neg_indices = [torch.from_numpy(np.nonzero(neg[s, b, :Q])[0]) for b in range(B)]
+            result.append((pos[s], neg_indices))
         return result
 
 

@@ -124,6 +124,21 @@ class PackedTargets:
         return self._maps
 
     @property
+    def image_index(self) -> np.ndarray:
+        """host int64 [M]: image of every packed target"""
+        if getattr(self, "_image_index", None) is None:
+            self._image_index = np.repeat(np.arange(self.batch, dtype=np.int64), self.sizes)
+        return self._image_index
+
+    @property
+    def local_index(self) -> np.ndarray:
+        """host int64 [M]: position of every packed target within its image"""
+        if getattr(self, "_local_index", None) is None:
+            self._local_index = np.arange(self.total, dtype=np.int64) - \
+                np.repeat(self.offsets_host[:-1].astype(np.int64), self.sizes)
+        return self._local_index
+
+    @property
     def batch_index(self) -> torch.Tensor:
         return self._pair_maps()[0]
 
