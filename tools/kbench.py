@@ -28,12 +28,13 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--which", default="cost,lap")
     ap.add_argument("--qpt", default="0", help="comma-separated codes for dm_debug_cost_queries_per_thread")
-    ap.add_argument("--lapmode", type=int, default=0)
+    ap.add_argument("--lapmode", default="0", help="comma-separated codes for dm_debug_force_generic_lap")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for code in args.qpt.split(","):
         lib.dm_debug_cost_queries_per_thread(int(code))
-    lib.dm_debug_force_generic_lap(args.lapmode)
+    for code in args.lapmode.split(","):
+        lib.dm_debug_force_generic_lap(int(code))
     wl, sets, targets = synth.make_workload(args.workload, device=dev, batch=args.batch)
     packed = PackedTargets(targets, dev)
     S, B, M = len(sets), packed.batch, packed.total
