@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Auxiliary assigners: all output sets of one step on the GPU (kernels + D2H + building the
+"""(Not collected by pytest; lives under tests/ because it times the CPU checker.)  Auxiliary assigners: all output sets of one step on the GPU (kernels + D2H + building the
 index lists) next to the numpy restatement of the reference's per-image loops on the host."""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 import torch
 
