@@ -142,9 +142,23 @@ def stress_roofline(device, launches=20):
     ms = e0.elapsed_time(e1) / launches
     algo = cost_kernel_bytes(wl.set_queries, wl.n_logits, packed.sizes)
     achieved = algo / (ms * 1e-3) / 1e9
+    del cost, sets
+    # what a plain streaming kernel reaches on this GPU: a 1 GiB device-to-device copy (read + write)
+    a = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(device)
+    copy_gbs = 2 * a.numel() * 4 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+    del a, b
     return {"workload": "cfg4 cost kernel only: B=256, Q=900, C=91, heavy-tail T, 6 sets", "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic("cost_tile_kernel", "cfg4"),
+            "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
             "kernel": "cost_tile_kernel", "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms}
 
 

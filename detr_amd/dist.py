@@ -33,10 +33,16 @@ def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> tor
 
     One collective for all S output sets.  It can be issued right after the targets are
     packed; it does not depend on the assignment."""
-    counts = torch.tensor(list(local_counts), dtype=torch.float32, device=device)
+    device = torch.device(device)
+    if device.type == "cuda":
+        # pinned staging + asynchronous copy: the host does not wait for the stream
+        staged = torch.tensor(list(local_counts), dtype=torch.float32).pin_memory()
+        counts = staged.to(device, non_blocking=True)
+    else:
+        counts = torch.tensor(list(local_counts), dtype=torch.float32, device=device)
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
         if world > 1:
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-            counts = counts / world
+            counts.div_(world)
     return counts.clamp_(min=1.0)
