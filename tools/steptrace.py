@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Host timeline of one match_many step (perf_counter stamps between its phases)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import detr_amd
+from detr_amd import synth
+from detr_amd.matcher import PackedTargets, _raise_for_status
+
+wl, sets, targets = synth.make_workload(sys.argv[1] if len(sys.argv) > 1 else "cfg2", device="cuda")
+m = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+dev = torch.device("cuda", 0)
+N = 300
+acc = np.zeros(6)
+for it in range(N + 20):
+    t0 = time.perf_counter()
+    packed = PackedTargets(targets, dev)
+    t1 = time.perf_counter()
+    out, queries, cost, strides = m._launch(sets, packed)
+    t2 = time.perf_counter()
+    host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
+    host.copy_(out, non_blocking=True)
+    if os.environ.get("SYNC_BEFORE_SPLIT"):
+        torch.cuda.current_stream(dev).synchronize()
+    t3 = time.perf_counter()
+    res = m._split(host, len(sets), packed.total, packed.sizes, queries, packed.offsets_host)
+    t4 = time.perf_counter()
+    torch.cuda.current_stream(dev).synchronize()
+    t5 = time.perf_counter()
+    _raise_for_status(int(host[-1]) & 0xFFFFFFFF)
+    t6 = time.perf_counter()
+    if it >= 20:
+        acc += np.diff([t0, t1, t2, t3, t4, t5, t6])
+names = ["pack", "launch", "d2h enqueue", "split", "sync wait", "status"]
+for n, v in zip(names, acc / N * 1e6):
+    print(f"{n:12s} {v:8.1f} us")
+print(f"{'total':12s} {acc.sum() / N * 1e6:8.1f} us")
