@@ -223,6 +223,22 @@ class HungarianMatcher(torch.nn.Module):
         self.focal_alpha = focal_alpha
         self.focal_gamma = focal_gamma
         self.last_status = None
+        self._events = {}
+
+    def __getstate__(self):
+        # per-device events and the last status view belong to this process and its streams
+        state = self.__dict__.copy()
+        state["_events"] = {}
+        state["last_status"] = None
+        return state
+
+    def _done_event(self, device) -> torch.cuda.Event:
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ev = self._events.get(key)
+        if ev is None:
+            with torch.cuda.device(device):
+                ev = self._events[key] = torch.cuda.Event()
+        return ev
 
     def _params(self) -> DmParams:
         return DmParams(0 if self.cls_loss == "ce" else 1, float(self.cost_class), float(self.cost_bbox),
@@ -321,9 +337,14 @@ class HungarianMatcher(torch.nn.Module):
         else:
             host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
             host.copy_(out, non_blocking=True)
+            done = self._done_event(device)
+            done.record()
             # the per-image views depend on shapes only: build them while the GPU is working
             result = self._split(host, S, M, sizes, queries, packed.offsets_host)
-            torch.cuda.current_stream(device).synchronize()
+            # by now the copy has normally landed: one event query is several times cheaper than a
+            # stream synchronisation, which is only the fallback
+            if not done.query():
+                done.synchronize()
             _raise_for_status(int(host[-1]) & 0xFFFFFFFF)
         if return_cost:
             costs = [cost[o:o + M * st].view(M, st)[:, :q] for (o, st), q in zip(strides, queries)]

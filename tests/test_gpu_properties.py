@@ -114,3 +114,20 @@ def test_dtype_and_shape_errors():
         matcher({"pred_logits": outputs["pred_logits"].double(), "pred_boxes": outputs["pred_boxes"]}, targets)
     with pytest.raises(ValueError):
         matcher(outputs, targets[:-1])
+
+
+def test_matcher_survives_deepcopy_and_pickle_after_use():
+    """The criterion that owns the matcher is an nn.Module that users copy and checkpoint."""
+    import copy
+    import pickle
+
+    import detr_amd
+
+    g = golden_io.load("ce_c3_q50")
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    base = matcher(outputs, targets)
+    for clone in (copy.deepcopy(matcher), pickle.loads(pickle.dumps(matcher))):
+        got = clone(outputs, targets)
+        for (a0, a1), (b0, b1) in zip(base, got):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)

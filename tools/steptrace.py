@@ -16,6 +16,7 @@ wl, sets, targets = synth.make_workload(sys.argv[1] if len(sys.argv) > 1 else "c
 m = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
 dev = torch.device("cuda", 0)
 N = 300
+EV = torch.cuda.Event() if os.environ.get("USE_EVENT") else None
 acc = np.zeros(6)
 for it in range(N + 20):
     t0 = time.perf_counter()
@@ -25,12 +26,18 @@ for it in range(N + 20):
     t2 = time.perf_counter()
     host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
     host.copy_(out, non_blocking=True)
+    if EV is not None:
+        EV.record()
     if os.environ.get("SYNC_BEFORE_SPLIT"):
         torch.cuda.current_stream(dev).synchronize()
     t3 = time.perf_counter()
     res = m._split(host, len(sets), packed.total, packed.sizes, queries, packed.offsets_host)
     t4 = time.perf_counter()
-    torch.cuda.current_stream(dev).synchronize()
+    if EV is not None:
+        while not EV.query():
+            pass
+    else:
+        torch.cuda.current_stream(dev).synchronize()
     t5 = time.perf_counter()
     _raise_for_status(int(host[-1]) & 0xFFFFFFFF)
     t6 = time.perf_counter()
