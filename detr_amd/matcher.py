@@ -35,24 +35,31 @@ class PackedTargets:
     """
 
     def __init__(self, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device):
-        self.sizes = [int(t["boxes"].shape[0]) for t in targets]
-        self.batch = len(self.sizes)
-        for t, n in zip(targets, self.sizes):
-            if int(t["labels"].shape[0]) != n:
-                raise ValueError("a target's labels and boxes differ in length")
-        self.total = sum(self.sizes)
-        self.max_t = max(self.sizes) if self.sizes else 0
+        sizes, label_list, box_list = [], [], []
+        for t in targets:                       # one pass over the dicts
+            b = t["boxes"]
+            sizes.append(b.shape[0])
+            label_list.append(t["labels"])
+            box_list.append(b)
+        self.sizes = sizes
+        self.batch = len(sizes)
+        self.total = sum(sizes)
+        self.max_t = max(sizes) if sizes else 0
         self.device = device
         if self.total > 0:
-            labels = torch.cat([t["labels"] for t in targets])
-            boxes = torch.cat([t["boxes"] for t in targets])
+            labels = torch.cat(label_list)
+            boxes = torch.cat(box_list)
             if boxes.device != device or labels.device != device:
                 raise ValueError("targets and predictions must be on the same device")
             if boxes.dtype != torch.float32:
                 raise RuntimeError(f"target boxes must be float32, got {boxes.dtype}")
+            if labels.shape[0] != self.total:
+                raise ValueError("a target's labels and boxes differ in length")
             self.labels = labels.to(torch.int64).contiguous()
             self.boxes = boxes.reshape(-1, 4).contiguous()
         else:
+            if any(int(t.shape[0]) for t in label_list):
+                raise ValueError("a target's labels and boxes differ in length")
             self.labels = torch.zeros(1, dtype=torch.int64, device=device)
             self.boxes = torch.zeros(1, 4, dtype=torch.float32, device=device)
         meta = np.empty(2 * self.batch + 1, dtype=np.int32)
