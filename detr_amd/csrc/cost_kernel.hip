@@ -12,9 +12,8 @@
 //   cost_small_kernel  C <= 4: the logits go straight to registers and the class cost of
 //                      every class is computed once per query.
 //   cost_tile_kernel   C > 4: a workgroup of four wavefronts shares one tile of 64 logit
-//                      rows, streamed with coalesced loads into LDS (odd row stride, so each
-//                      lane reads its own row conflict-free); the wavefronts split the
-//                      targets four ways.
+//                      rows, streamed into LDS as a linear image (LDS-DMA); the wavefronts
+//                      split the targets four ways.
 //
 // HBM-bound streaming work: no contraction, so no MFMA.  Compiled with -ffp-contract=off;
 // the two divisions of the GIoU are evaluated as reciprocal * numerator (v_rcp_f32, 1 ulp)
@@ -273,8 +272,10 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
 
 // C > 4.  blockDim = 64 * W: wavefront w of the workgroup handles targets t = w (mod W) of one
 // tile of 64 queries of one image, two targets per trip (two independent dependency chains per
-// lane); all W wavefronts stream the 64 x C logit tile into LDS together (LDS-DMA where the rows
-// allow it: no registers, every piece in flight at once).
+// lane); all W wavefronts stream the 64 x C logit tile into LDS together as a linear image of the
+// rows (LDS-DMA when the tile starts on a 16-byte boundary: no registers, every piece in flight at
+// once).  Lane l reads row l: with an odd C the row stride is odd and the lanes hit distinct banks;
+// with an even C lane l walks its row rotated by l columns, which has the same effect.
 // One-dimensional grid, workgroup id = (set * B + image) * ntiles + tile.  (Giving all tiles of an
 // image to workgroups of one XCD, so that the 256-byte pieces of a cost row meet in one L2, measured
 // 5 % slower: it concentrates the heavy images on single XCDs.)
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     extern __shared__ __align__(16) unsigned char smem[];
     TgtRec *tg = reinterpret_cast<TgtRec *>(smem);                                   // [TCHUNK]
     float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [8][64] softmax partials
-    float *tile = part + (MODE == 0 ? 64 * 8 : 0);                                   // [64][Cs]
+    float *tile = part + (MODE == 0 ? 64 * 8 : 0);                                   // [64][C]
 
     const int unit = blockIdx.x / ntiles, tile_id = blockIdx.x - unit * ntiles;
     if (unit >= nsets * B) return;
@@ -306,21 +307,18 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     const int t0 = tgt_off[b];
     const int T = tgt_off[b + 1] - t0;
     const size_t row = (size_t)b * Q + (active ? q : Q - 1);
-    const int Cs = C | 1;                      // odd LDS row stride
 
     const float4 raw = reinterpret_cast<const float4 *>(set.boxes)[row];
     if (T > 0) {
-        // stream the tile: rows q0 .. q0+nq-1 are contiguous in memory; lane-consecutive dwords
-        // land on consecutive LDS banks
+        // stream the tile: rows q0 .. q0+nq-1 are contiguous in memory and stay so in LDS
         const float *src = set.logits + ((size_t)b * Q + q0) * (size_t)C;
         const int n = nq * C;
 #if DM_TILE_ABL == 2
         if (false) {
 #else
-        if ((C & 1) && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
 #endif
-            // odd C: the LDS image (row stride C) is a linear copy of the rows -> LDS-DMA, 1 KB per
-            // wave instruction
+            // LDS-DMA, 1 KB per wave instruction
             for (int base = wave * 256; base < n; base += W * 256) {
                 const int e = base + lane * 4;
                 if (e + 3 < n)
@@ -335,22 +333,15 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
 #else
         } else {
 #endif
-            const int step_r = NT / C, step_c = NT % C;
-            int r = tid / C, c = tid - r * C;
             constexpr int UL = 8;
             for (int base = 0; base < n; base += NT * UL) {
                 float v[UL];
 #pragma unroll
-                for (int k = 0; k < UL; ++k) {
-                    const int e = base + k * NT + tid;
-                    v[k] = src[min(e, n - 1)];
-                }
+                for (int k = 0; k < UL; ++k) v[k] = src[min(base + k * NT + tid, n - 1)];
 #pragma unroll
                 for (int k = 0; k < UL; ++k) {
                     const int e = base + k * NT + tid;
-                    if (e < n) tile[r * Cs + c] = v[k];
-                    c += step_c; r += step_r;
-                    if (c >= C) { c -= C; ++r; }
+                    if (e < n) tile[e] = v[k];
                 }
             }
         }
@@ -361,14 +352,17 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     if (T == 0) return;
     __syncthreads();
 
-    const float *xr = tile + lane * Cs;
-    float ce_max = 0.0f, ce_den = 1.0f;
+    const float *xr = tile + lane * C;
+    float ce_max = 0.0f, ce_scale = 1.0f;
     if (MODE == 0) {
-        // softmax statistics of the lane's row: the classes form 8 residue classes (mod 8) that the
-        // wavefronts share out; the partial sums meet in a fixed tree, so the result does not
-        // depend on the number of wavefronts
+        // softmax statistics of the lane's row.  Column order of the walk: k -> (k + rot) mod C, rot =
+        // lane for even C (bank spreading), 0 otherwise.  The walk positions form 8 residue classes
+        // (mod 8) that the wavefronts share out; the partial sums meet in a fixed tree, so the result
+        // does not depend on the number of wavefronts.
+        const int rot = (C & 1) ? 0 : lane;
+        auto at = [&](int k) { const int c = k + rot; return xr[c >= C ? c - C : c]; };
         float mx = -__builtin_huge_valf();
-        for (int c = wave; c < C; c += W) mx = fmaxf(mx, xr[c]);
+        for (int k = wave; k < C; k += W) mx = fmaxf(mx, at(k));
         part[wave * 64 + lane] = mx;
         __syncthreads();
         mx = part[lane];
@@ -377,7 +371,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
         __syncthreads();
         for (int r = wave; r < 8; r += W) {
             float den = 0.0f;
-            for (int c = r; c < C; c += 8) den += expf(xr[c] - mx);
+            for (int k = r; k < C; k += 8) den += __builtin_amdgcn_exp2f((at(k) - mx) * 1.44269504088896f);
             part[r * 64 + lane] = den;
         }
         __syncthreads();
@@ -389,7 +383,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
         for (int h = 4; h >= 1; h /= 2)
 #pragma unroll
             for (int r = 0; r < h; ++r) dsum[r] = dsum[2 * r] + dsum[2 * r + 1];
-        ce_den = dsum[0];
+        ce_scale = -1.0f / dsum[0];       // class cost = -softmax = exp(x - max) * (-1 / sum)
     }
 
     const int qs = set.q_stride;
@@ -411,7 +405,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
                 const TgtRec g = tg[i];
                 const float xl = xr[g.label];
                 float cls;
-                if (MODE == 0) cls = -(expf(xl - ce_max) / ce_den);
+                if (MODE == 0) cls = __builtin_amdgcn_exp2f((xl - ce_max) * 1.44269504088896f) * ce_scale;
                 else cls = focal_cost<MODE == 1>(xl, prm.focal_alpha, prm.focal_gamma);
                 return pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
             };
@@ -497,7 +491,7 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     const int mode = params->cls_mode == 0 ? 0 : (params->focal_gamma == 2.0f ? 1 : 2);
     const int tile_waves = g_tile_waves == 8 ? 8 : 4;
     const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 8 * sizeof(float) : 0) +
-                            (size_t)64 * (C | 1) * sizeof(float);
+                            (size_t)64 * C * sizeof(float);
     if (tile && tile_lds > 160 * 1024) return DM_E_UNSUPPORTED;
     typedef void (*TileFn)(const DmSetArray, const int, const int, const int, const int64_t *, const float *,
                            const int32_t *, const DmParams, float *, int32_t *, const int);

@@ -41,6 +41,8 @@ WORKLOADS = {
     # COCO-like stress
     "cfg4": Workload("cfg4", 256, [900] * 6, 91, 91, "focal", "heavy_tail", dict(cls_loss="focal", **_W), 4000),
     # Co-DETR scale: 6 layers x 2 heads
+    # cfg4 with the softmax class cost of the reference's 'ce' models: 91 classes + no-object = 92 logits
+    "cfg4_ce": Workload("cfg4_ce", 256, [900] * 6, 92, 91, "ce", "heavy_tail", dict(cls_loss="ce", **_W), 4000),
     "cfg5": Workload("cfg5", 1024, [600] * 12, 2, 2, "focal", "poisson16", dict(cls_loss="focal", **_W), 5000),
 }
 
