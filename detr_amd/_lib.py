@@ -41,7 +41,7 @@ class DmParams(ctypes.Structure):
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_profile_enable", "dm_profile_read",
-           "dm_debug_force_generic_lap", "dm_debug_cost_queries_per_thread",
+           "dm_debug_set_knob",
            "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
            "dm_atss_f32", "dm_frcnn_f32"]
 
@@ -79,10 +79,8 @@ def _load():
     lib.dm_atss_f32.argtypes = [isetp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.dm_frcnn_f32.restype = ctypes.c_int
     lib.dm_frcnn_f32.argtypes = [isetp, i32, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp, vp]
-    lib.dm_debug_force_generic_lap.restype = None
-    lib.dm_debug_force_generic_lap.argtypes = [ctypes.c_int]
-    lib.dm_debug_cost_queries_per_thread.restype = None
-    lib.dm_debug_cost_queries_per_thread.argtypes = [ctypes.c_int]
+    lib.dm_debug_set_knob.restype = ctypes.c_int
+    lib.dm_debug_set_knob.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.dm_profile_enable.restype = ctypes.c_int
     lib.dm_profile_enable.argtypes = [ctypes.c_int]
     lib.dm_profile_read.restype = ctypes.c_int
@@ -93,6 +91,14 @@ def _load():
 
 
 lib = _load()
+
+
+#: launch-shape knobs of dm_debug_set_knob (testing / tuning aid; 0 = automatic)
+KNOBS = {"lap_kernel": 0, "lap_max_waves": 1, "cost_qpt": 2, "cost_tsplit": 3, "tile_waves": 4}
+
+
+def set_knob(name: str, value: int):
+    check(lib.dm_debug_set_knob(KNOBS[name], int(value)), f"dm_debug_set_knob({name}, {value})")
 
 
 def check(rc, what):

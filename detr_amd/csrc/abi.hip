@@ -14,6 +14,23 @@ extern "C" const char *dm_strerror(int code)
     }
 }
 
+namespace dm {
+int set_cost_knob(int knob, int value);
+int set_lap_knob(int knob, int value);
+}  // namespace dm
+
+extern "C" int dm_debug_set_knob(int knob, int value)
+{
+    switch (knob) {
+    case DM_KNOB_LAP_KERNEL:
+    case DM_KNOB_LAP_MAX_WAVES: return dm::set_lap_knob(knob, value);
+    case DM_KNOB_COST_QPT:
+    case DM_KNOB_COST_TSPLIT:
+    case DM_KNOB_TILE_WAVES: return dm::set_cost_knob(knob, value);
+    }
+    return DM_E_INVALID_ARG;
+}
+
 extern "C" int dm_device_count(void)
 {
     int n = 0;

@@ -459,14 +459,27 @@ int g_cost_qpt = 0;   // 0: automatic; 1 / 2: force the queries-per-thread varia
 
 extern "C" const char *dm_last_hip_error(void) { return g_hip_err; }
 
-// Testing aid: 0 restores the automatic choice, 1 / 2 force one / two queries per thread in
-// the small-C cost kernel.
-extern "C" void dm_debug_cost_queries_per_thread(int qpt)
+namespace dm {
+// launch-shape knobs of the cost kernels (dm_debug_set_knob); 0 = automatic
+int set_cost_knob(int knob, int value)
 {
-    if (qpt >= 300) { g_tile_waves = qpt - 300; return; }     // 304 / 308: wavefronts per workgroup
-    if (qpt >= 200) { g_cost_tsplit = qpt - 200; return; }   // 201, 202, 204: forced target split
-    g_cost_qpt = (qpt == 1 || qpt == 2) ? qpt : 0;
+    switch (knob) {
+    case DM_KNOB_COST_QPT:
+        if (value < 0 || value > 2) return DM_E_INVALID_ARG;
+        g_cost_qpt = value;
+        return DM_OK;
+    case DM_KNOB_COST_TSPLIT:
+        if (value != 0 && value != 1 && value != 2 && value != 4) return DM_E_INVALID_ARG;
+        g_cost_tsplit = value;
+        return DM_OK;
+    case DM_KNOB_TILE_WAVES:
+        if (value != 0 && value != 4 && value != 8) return DM_E_INVALID_ARG;
+        g_tile_waves = value;
+        return DM_OK;
+    }
+    return DM_E_INVALID_ARG;
 }
+}  // namespace dm
 
 namespace dm {
 int check_hip(hipError_t e, const char *what)

@@ -869,13 +869,15 @@ int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const in
     if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
-    static bool big_lds_enabled = false;
-    if (fixed + want > 64 * 1024 && !big_lds_enabled) {
+    // the attribute belongs to the function on ONE device: remember per device where it is set
+    static unsigned long long big_lds_devices = 0;
+    int dev = 0;
+    if (fixed + want > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !(dev < 64 && ((big_lds_devices >> dev) & 1ull))) {
         int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_wave_kernel<NCOL>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
                                "hipFuncSetAttribute(lap_wave_kernel)");
         if (rc != DM_OK) return rc;
-        big_lds_enabled = true;
+        if (dev < 64) big_lds_devices |= 1ull << dev;
     }
     hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * B), dim3(64), fixed + want, st, arr, n, cost,
                        tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
@@ -927,13 +929,15 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
     if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
-    static bool big_lds_enabled = false;
-    if (fixed + want > 64 * 1024 && !big_lds_enabled) {
+    // the attribute belongs to the function on ONE device: remember per device where it is set
+    static unsigned long long big_lds_devices = 0;
+    int dev = 0;
+    if (fixed + want > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !(dev < 64 && ((big_lds_devices >> dev) & 1ull))) {
         int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_block_kernel<NCOL>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
                                "hipFuncSetAttribute(lap_block_kernel)");
         if (rc != DM_OK) return rc;
-        big_lds_enabled = true;
+        if (dev < 64) big_lds_devices |= 1ull << dev;
     }
     hipLaunchKernelGGL(lap_block_kernel<NCOL>, dim3((unsigned)n * B), dim3(64 * waves), fixed + want, st, arr, n,
                        cost, tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
@@ -955,14 +959,23 @@ int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, c
 
 }  // namespace
 
-// Testing aid: 0 restores the automatic choice of assignment kernel, 1 routes every problem
-// through the list-order kernel, 2 / 3 force the workgroup / wavefront register kernel for
-// the problems they can take.
-extern "C" void dm_debug_force_generic_lap(int mode)
+namespace dm {
+// launch-shape knobs of the assignment kernels (dm_debug_set_knob); 0 = automatic
+int set_lap_knob(int knob, int value)
 {
-    if (mode >= 100) { g_lap_max_waves = mode - 100; return; }    // 101..116: wavefronts per problem
-    g_lap_mode = mode;
+    switch (knob) {
+    case DM_KNOB_LAP_KERNEL:
+        if (value < 0 || value > 3) return DM_E_INVALID_ARG;
+        g_lap_mode = value;
+        return DM_OK;
+    case DM_KNOB_LAP_MAX_WAVES:
+        if (value < 0 || value > 16) return DM_E_INVALID_ARG;
+        g_lap_max_waves = value ? value : 16;
+        return DM_OK;
+    }
+    return DM_E_INVALID_ARG;
 }
+}  // namespace dm
 
 extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
                           const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out,

@@ -202,14 +202,16 @@ int dm_frcnn_f32(const DmIndexSet *sets, int S, int B, int M, int W, float pos_t
 int dm_profile_enable(int on);
 int dm_profile_read(float *cost_ms, float *lap_ms);
 
-/* Testing aid: which assignment kernel takes the problems it can take.  0: automatic choice,
- * 1: list-order kernel only, 2: workgroup-per-problem kernel, 3: wavefront-per-problem kernel. */
-void dm_debug_force_generic_lap(int mode);
-
-/* Testing aid: 0 automatic, 1 / 2 force one / two queries per thread in the C <= 4 cost kernel;
- * 201 / 202 / 204 force its target split (200 automatic); 304 / 308 set the wavefronts per
- * workgroup of the C > 4 cost kernel (300 automatic). */
-void dm_debug_cost_queries_per_thread(int qpt);
+/*
+ * Testing / tuning aid: launch-shape knobs.  None of them changes a result (the tests check that);
+ * value 0 restores the automatic choice.  Returns DM_OK or DM_E_INVALID_ARG.  Not thread-safe.
+ */
+#define DM_KNOB_LAP_KERNEL 0     /* 1: list-order kernel only, 2: workgroup-per-problem, 3: wavefront-per-problem */
+#define DM_KNOB_LAP_MAX_WAVES 1  /* 1..16: wavefronts per problem in the workgroup-per-problem kernel */
+#define DM_KNOB_COST_QPT 2       /* 1 / 2: queries per thread in the C <= 4 cost kernel */
+#define DM_KNOB_COST_TSPLIT 3    /* 1 / 2 / 4: workgroups sharing the targets of an image in the C <= 4 cost kernel */
+#define DM_KNOB_TILE_WAVES 4     /* 4 / 8: wavefronts per workgroup in the C > 4 cost kernel */
+int dm_debug_set_knob(int knob, int value);
 
 #ifdef __cplusplus
 }

@@ -113,11 +113,11 @@ def test_lsap_bit_exact_vs_scipy(force_generic):
 
     rng = np.random.default_rng(99)
     mats = _lsap_matrices(rng)
-    detr_amd.lib.dm_debug_force_generic_lap(force_generic)
+    detr_amd._lib.set_knob("lap_kernel", force_generic)
     try:
         got = detr_amd.batched_linear_sum_assignment([torch.from_numpy(m).cuda() for m in mats])
     finally:
-        detr_amd.lib.dm_debug_force_generic_lap(0)
+        detr_amd._lib.set_knob("lap_kernel", 0)
     for m, (r, c) in zip(mats, got):
         rs, cs = linear_sum_assignment(m)
         np.testing.assert_array_equal(r.numpy(), rs, err_msg=str(m.shape))
@@ -128,7 +128,7 @@ def test_lsap_errors():
     import detr_amd
 
     for force in (0, 1, 2, 3):
-        detr_amd.lib.dm_debug_force_generic_lap(force)
+        detr_amd._lib.set_knob("lap_kernel", force)
         try:
             for bad in (np.nan, -np.inf):
                 m = np.ones((30, 4), dtype=np.float32)
@@ -139,7 +139,7 @@ def test_lsap_errors():
             with pytest.raises(ValueError):
                 detr_amd.batched_linear_sum_assignment([torch.from_numpy(m).cuda()])
         finally:
-            detr_amd.lib.dm_debug_force_generic_lap(0)
+            detr_amd._lib.set_knob("lap_kernel", 0)
 
 
 def _check_workload(name, batch=None, lap_sample=None):
@@ -245,13 +245,15 @@ def test_cost_kernel_shape_knobs_do_not_change_the_cost(name):
     matcher = _matcher(**g.matcher_kwargs())
     base = [blk.clone() for blk in matcher.cost_blocks(outputs, targets)]
     try:
-        for code in (304, 308, 2, 1, 201, 202, 204):
-            detr_amd.lib.dm_debug_cost_queries_per_thread(code)
+        for knob, value in (("tile_waves", 4), ("tile_waves", 8), ("cost_qpt", 2), ("cost_qpt", 1),
+                            ("cost_tsplit", 1), ("cost_tsplit", 2), ("cost_tsplit", 4)):
+            detr_amd._lib.set_knob(knob, value)
             for a, b in zip(base, matcher.cost_blocks(outputs, targets)):
-                assert torch.equal(a, b), code
+                assert torch.equal(a, b), (knob, value)
+            detr_amd._lib.set_knob(knob, 0)
     finally:
-        for code in (300, 200, 0):
-            detr_amd.lib.dm_debug_cost_queries_per_thread(code)
+        for knob in ("tile_waves", "cost_qpt", "cost_tsplit"):
+            detr_amd._lib.set_knob(knob, 0)
 
 
 def test_image_order_invariance():

@@ -27,14 +27,13 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--which", default="cost,lap")
-    ap.add_argument("--qpt", default="0", help="comma-separated codes for dm_debug_cost_queries_per_thread")
-    ap.add_argument("--lapmode", default="0", help="comma-separated codes for dm_debug_force_generic_lap")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="launch-shape knob, e.g. lap_kernel=3, lap_max_waves=5, cost_tsplit=2, tile_waves=8")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    for code in args.qpt.split(","):
-        lib.dm_debug_cost_queries_per_thread(int(code))
-    for code in args.lapmode.split(","):
-        lib.dm_debug_force_generic_lap(int(code))
+    for kv in args.knob:
+        name, value = kv.split("=")
+        detr_amd._lib.set_knob(name, int(value))
     wl, sets, targets = synth.make_workload(args.workload, device=dev, batch=args.batch)
     packed = PackedTargets(targets, dev)
     S, B, M = len(sets), packed.batch, packed.total

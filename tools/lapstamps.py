@@ -16,7 +16,7 @@ from detr_amd import synth
 from detr_amd._lib import DmSet
 from detr_amd.matcher import PackedTargets
 lib = ctypes.CDLL(so)
-lib.dm_debug_force_generic_lap(int(os.environ.get("DM_LAPMODE", "0")))
+lib.dm_debug_set_knob(0, int(os.environ.get("DM_LAPMODE", "0")))      # knob 0: which assignment kernel
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 dev = torch.device("cuda", 0)
 wl, sets, targets = synth.make_workload(name, device=dev)
