@@ -101,16 +101,17 @@ def cpu_baseline(wl, sets, targets, min_s=10.0, budget_s=20.0):
     }
 
 
-def stress_roofline(device, launches=20):
-    """Cost kernel alone at the cfg4 size (B=256, Q=900, C=91, heavy-tail T, 6 sets: 0.65 GB of
-    algorithmic traffic per launch), the size at which an HBM-roofline fraction is meaningful.
-    Timed with events on the launch stream over back-to-back launches through the C ABI."""
+def stress_roofline(device, launches=20, workload="cfg4", copy_reference=True):
+    """Cost kernel alone, timed with two events on the launch stream around `launches` back-to-back
+    launches through the C ABI (no per-launch event bracket, no other work in between).
+    Default: the cfg4 size (B=256, Q=900, C=91, heavy-tail T, 6 sets: 0.65 GB of algorithmic traffic
+    per launch), the size at which an HBM-roofline fraction is meaningful."""
     import detr_amd
     from detr_amd import synth
     from detr_amd._lib import DmSet, lib
     from detr_amd.matcher import PackedTargets
 
-    wl, sets, targets = synth.make_workload("cfg4", device=device)
+    wl, sets, targets = synth.make_workload(workload, device=device)
     packed = PackedTargets(targets, device)
     S, M = len(sets), packed.total
     arr = (DmSet * S)()
@@ -144,6 +145,12 @@ def stress_roofline(device, launches=20):
     algo = cost_kernel_bytes(wl.set_queries, wl.n_logits, packed.sizes)
     achieved = algo / (ms * 1e-3) / 1e9
     del cost, sets
+    kernel = "cost_small_kernel" if wl.n_logits <= 4 else "cost_tile_kernel"
+    if not copy_reference:
+        return {"workload": f"{workload} cost kernel only, back-to-back launches", "bound": "hbm", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(kernel, workload), "kernel": kernel,
+                "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms}
     # what a plain streaming kernel reaches on this GPU: a 1 GiB device-to-device copy (read + write)
     a = torch.empty(1 << 28, dtype=torch.float32, device=device)
     b = torch.empty_like(a)
@@ -314,6 +321,8 @@ def main():
         if world == 1:
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
         if world == 1 and not args.no_stress:
+            record["roofline_back_to_back"] = stress_roofline(device, launches=200, workload=wl.name,
+                                                              copy_reference=False)
             record["roofline_stress"] = stress_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             record["cpu_baseline"] = cpu_baseline(wl, sets, targets)
