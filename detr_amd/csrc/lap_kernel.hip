@@ -1004,9 +1004,41 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
         if (needs_generic && (Q > GENERIC_MAX || max_T > GENERIC_MAX)) return DM_E_UNSUPPORTED;
     }
 
+    bool done[4096] = {false};
+    if (!(g_lap_mode == 1) && (g_lap_mode == 0 || g_lap_mode == 2)) {
+        // Sets of different Q (decoder layers + a first-stage set over all encoder tokens) in ONE
+        // launch shaped for the largest Q, when that does not squeeze the wavefronts per problem:
+        // the kernel is latency-bound, idle lanes cost nothing, and the launches no longer queue
+        // behind each other.
+        int max_Q = 0, count = 0, distinct = 0;
+        for (int s = 0; s < S; ++s) {
+            if (sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q) continue;
+            bool seen = false;
+            for (int r = 0; r < s; ++r) seen |= sets[r].Q == sets[s].Q && !(sets[r].Q > FAST_MAX_Q || max_T >= sets[r].Q);
+            distinct += seen ? 0 : 1;
+            max_Q = std::max(max_Q, sets[s].Q);
+            ++count;
+        }
+        const long long P = (long long)count * B;
+        int ncol = 1, waves = 1;
+        if (distinct > 1) pick_shape(max_Q, P, &ncol, &waves);
+        // ... as long as all workgroups are resident at once (8192 wavefront slots on the chip)
+        if (distinct > 1 && count <= DM_MAX_SETS_PER_LAUNCH && P * waves <= 8192) {
+            DmSetArray arr;
+            int n = 0, max_stride = max_Q;
+            for (int s = 0; s < S; ++s) {
+                if (sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q) continue;
+                arr.s[n++] = sets[s];
+                done[s] = true;
+                max_stride = std::max(max_stride, sets[s].q_stride);
+            }
+            int rc = launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out,
+                                      tgt_out, status, st);
+            if (rc != DM_OK) return rc;
+        }
+    }
     if (!(g_lap_mode == 1)) {
-        // one launch per distinct Q among the sets the register kernel can take
-        bool done[4096] = {false};
+        // one launch per distinct Q among the (remaining) sets the register kernel can take
         for (int s0 = 0; s0 < S; ++s0) {
             const int Q = sets[s0].Q;
             if (done[s0] || Q > FAST_MAX_Q) continue;
