@@ -37,6 +37,7 @@ constexpr int FAST_MAX_NCOL = 17;
 constexpr int FAST_MAX_Q = 64 * FAST_MAX_NCOL;
 constexpr int GENERIC_MAX = 4096;
 
+int g_lap_wave_budget = 0;   // 0: automatic (12288); otherwise wavefronts a launch of lap_block_kernel may ask for
 int g_lap_lds_kb = 0;        // 0: automatic; otherwise LDS budget per problem in KB (tuning knob)
 int g_lap_max_waves = 16;   // wavefronts per problem in lap_block_kernel (tuning knob)
 int g_lap_mode = 0;   // 0: automatic; 1: list-order kernel only; 2: workgroup kernel; 3: wavefront kernel
@@ -909,7 +910,8 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
 {
     const int need = (Q + 63) / 64;                    // 64-column slices
     long long w = need;
-    const long long wave_budget = 6144;                // about 24 wavefronts per CU
+    // 1.5 x the chip's wavefront slots: the heaviest problems come first and the tail back-fills (measured)
+    const long long wave_budget = g_lap_wave_budget ? g_lap_wave_budget : 12288;
     if (P * need > wave_budget) w = wave_budget / P;
     if (w > g_lap_max_waves) w = g_lap_max_waves;
     if (w < 1) w = 1;
@@ -974,6 +976,10 @@ int set_lap_knob(int knob, int value)
     case DM_KNOB_LAP_KERNEL:
         if (value < 0 || value > 3) return DM_E_INVALID_ARG;
         g_lap_mode = value;
+        return DM_OK;
+    case DM_KNOB_LAP_WAVE_BUDGET:
+        if (value < 0 || value > (1 << 20)) return DM_E_INVALID_ARG;
+        g_lap_wave_budget = value;
         return DM_OK;
     case DM_KNOB_LAP_LDS_KB:
         if (value < 0 || value > 80) return DM_E_INVALID_ARG;

@@ -212,6 +212,7 @@ int dm_profile_read(float *cost_ms, float *lap_ms);
 #define DM_KNOB_COST_TSPLIT 3    /* 1 / 2 / 4: workgroups sharing the targets of an image in the C <= 4 cost kernel */
 #define DM_KNOB_TILE_WAVES 4     /* 4 / 8: wavefronts per workgroup in the C > 4 cost kernel */
 #define DM_KNOB_LAP_LDS_KB 5     /* 1..80: LDS budget per problem of the register assignment kernels, in KB */
+#define DM_KNOB_LAP_WAVE_BUDGET 6  /* wavefronts one launch of the workgroup-per-problem kernel may ask for */
 int dm_debug_set_knob(int knob, int value);
 
 #ifdef __cplusplus
