@@ -1054,7 +1054,10 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
             // wavefront per problem (throughput)
             int ncol = ncol_class(Q), waves = 1;
             const long long P = (long long)total * B;
-            const bool use_block = g_lap_mode == 2 || (g_lap_mode == 0 && P * ((Q + 63) / 64) <= 20480);   // measured crossover
+            // crossover measured at Q=600, T~16: 20480 column slices; problems with many rows (T up to
+            // 100 at Q=900) stay faster in the workgroup kernel well beyond that
+            const long long slices = P * ((Q + 63) / 64);
+            const bool use_block = g_lap_mode == 2 || (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 20480));
             if (use_block) pick_shape(Q, P, &ncol, &waves);
             DmSetArray arr;
             int n = 0, max_stride = Q;

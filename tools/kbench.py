@@ -86,6 +86,14 @@ def main():
     if "lap" in args.which:
         us = timeit(run_lap, args.iters)
         print(f"lap : {us:8.2f} us/launch  {S * B / us:8.2f} problems/us  (P={S * B}, max T={packed.max_t})")
+    if "match" in args.which:
+        def run_match():
+            rc = lib.dm_match_f32(arr, S, B, C, packed.labels.data_ptr(), packed.boxes.data_ptr(), packed.offsets_ptr,
+                                  packed.order_ptr, packed.max_t, ctypes.byref(prm), cost.data_ptr(), out.data_ptr(),
+                                  out.data_ptr() + 8 * S * M, status, stream)
+            assert rc == 0, rc
+        us = timeit(run_match, args.iters)
+        print(f"match: {us:7.2f} us per dm_match_f32 (cost kernel in the targets' processing order)")
     if "both" in args.which:
         def run_both():
             run_cost()
