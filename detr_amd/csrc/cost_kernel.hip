@@ -547,9 +547,9 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
                     const int threads = 64 * pick_waves(lanes, 8);
                     // few wavefronts in flight: split every image's targets over 2 or 4 workgroups
                     const long long waves_total = (long long)((lanes + 63) / 64) * B * n;
-                    int tsplit = 1;      // measured on MI355X: 4-way below ~1k wavefronts, 2-way below ~8k
+                    int tsplit = 1;      // measured on MI355X: 4-way below ~1k wavefronts, 2-way below ~6k
                     if (waves_total <= 1024 && max_T >= 8) tsplit = 4;
-                    else if (waves_total <= 8192 && max_T >= 4) tsplit = 2;
+                    else if (waves_total <= 6144 && max_T >= 4) tsplit = 2;
                     if (g_cost_tsplit) tsplit = g_cost_tsplit;
                     dim3 grid(((lanes + threads - 1) / threads) * tsplit, B, n);
 #define DM_LAUNCH_SMALL(CC, QQ)                                                                                  \
