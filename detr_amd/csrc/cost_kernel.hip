@@ -290,8 +290,8 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     constexpr int NT = 64 * W;
     extern __shared__ __align__(16) unsigned char smem[];
     TgtRec *tg = reinterpret_cast<TgtRec *>(smem);                                   // [TCHUNK]
-    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [8][64] softmax partials
-    float *tile = part + (MODE == 0 ? 64 * 8 : 0);                                   // [64][C]
+    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [16][64] softmax partials
+    float *tile = part + (MODE == 0 ? 64 * 16 : 0);                                   // [64][C]
 
     const int unit = blockIdx.x / ntiles, tile_id = blockIdx.x - unit * ntiles;
     if (unit >= nsets * B) return;
@@ -353,37 +353,62 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     __syncthreads();
 
     const float *xr = tile + lane * C;
-    float ce_max = 0.0f, ce_scale = 1.0f;
+    constexpr float LOG2E = 1.44269504088896f;
+    float ce_max = 0.0f, ce_scale = 1.0f;      // softmax in base 2: p = exp2(x * LOG2E - ce_max) * (-ce_scale)
     if (MODE == 0) {
-        // softmax statistics of the lane's row.  Column order of the walk: k -> (k + rot) mod C, rot =
-        // lane for even C (bank spreading), 0 otherwise.  The walk positions form 8 residue classes
-        // (mod 8) that the wavefronts share out; the partial sums meet in a fixed tree, so the result
-        // does not depend on the number of wavefronts.
+        // Softmax statistics of the lane's row in ONE pass over the tile.  The walk over the row is
+        // k -> column (k + rot) mod C, rot = lane for even C (bank spreading), 0 otherwise.  The walk
+        // positions form 16 residue classes (mod 16); a wavefront runs its 16 / W classes as
+        // independent chains side by side.  A chain keeps a running maximum m and the sum s of
+        // exp2(t - m), rescaled when m grows (one exponential per element either way).  Chains c and
+        // c + 8 always sit in the same wavefront and are merged there; the 8 merged pairs meet in LDS
+        // and are merged in a fixed order, so the result does not depend on the number of wavefronts.
+        constexpr int NCH = 16 / W;
         const int rot = (C & 1) ? 0 : lane;
-        auto at = [&](int k) { const int c = k + rot; return xr[c >= C ? c - C : c]; };
-        float mx = -__builtin_huge_valf();
-        for (int k = wave; k < C; k += W) mx = fmaxf(mx, at(k));
-        part[wave * 64 + lane] = mx;
-        __syncthreads();
-        mx = part[lane];
+        float m[NCH], sum[NCH];
 #pragma unroll
-        for (int w = 1; w < W; ++w) mx = fmaxf(mx, part[w * 64 + lane]);
-        __syncthreads();
-        for (int r = wave; r < 8; r += W) {
-            float den = 0.0f;
-            for (int k = r; k < C; k += 8) den += __builtin_amdgcn_exp2f((at(k) - mx) * 1.44269504088896f);
-            part[r * 64 + lane] = den;
+        for (int i = 0; i < NCH; ++i) { m[i] = -3.0e38f; sum[i] = 0.0f; }   // finite start: a -inf logit adds 0
+        auto take = [&](int i, int k) {
+            int c = k + rot;
+            c = c >= C ? c - C : c;
+            const float t = xr[c] * LOG2E;
+            const float d = t - m[i];
+            const float e = __builtin_amdgcn_exp2f(-fabsf(d));
+            sum[i] = d > 0.0f ? __builtin_fmaf(sum[i], e, 1.0f) : sum[i] + e;
+            m[i] = fmaxf(m[i], t);
+        };
+        int k0 = 0;
+        for (; k0 + 16 <= C; k0 += 16) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) take(i, k0 + wave + W * i);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (k0 + wave + W * i < C) take(i, k0 + wave + W * i);
+#pragma unroll
+        for (int i = 0; i < NCH / 2; ++i) {       // classes wave + W*i and wave + W*i + 8
+            const int j = i + NCH / 2;
+            const float mm = fmaxf(m[i], m[j]);
+            const float s2 = __builtin_fmaf(sum[i], __builtin_amdgcn_exp2f(m[i] - mm),
+                                            sum[j] * __builtin_amdgcn_exp2f(m[j] - mm));
+            part[(wave + W * i) * 64 + lane] = mm;
+            part[(8 + wave + W * i) * 64 + lane] = s2;
         }
         __syncthreads();
-        ce_max = mx;
-        float dsum[8];
+        float ms[8], ss[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) dsum[r] = part[r * 64 + lane];
+        for (int r = 0; r < 8; ++r) { ms[r] = part[r * 64 + lane]; ss[r] = part[(8 + r) * 64 + lane]; }
+        float mx = ms[0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) mx = fmaxf(mx, ms[r]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ss[r] *= __builtin_amdgcn_exp2f(ms[r] - mx);
 #pragma unroll
         for (int h = 4; h >= 1; h /= 2)
 #pragma unroll
-            for (int r = 0; r < h; ++r) dsum[r] = dsum[2 * r] + dsum[2 * r + 1];
-        ce_scale = -1.0f / dsum[0];       // class cost = -softmax = exp(x - max) * (-1 / sum)
+            for (int r = 0; r < h; ++r) ss[r] = ss[2 * r] + ss[2 * r + 1];
+        ce_max = mx;
+        ce_scale = -1.0f / ss[0];       // class cost = -softmax
     }
 
     const int qs = set.q_stride;
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
                 const TgtRec g = tg[i];
                 const float xl = xr[g.label];
                 float cls;
-                if (MODE == 0) cls = __builtin_amdgcn_exp2f((xl - ce_max) * 1.44269504088896f) * ce_scale;
+                if (MODE == 0) cls = __builtin_amdgcn_exp2f(__builtin_fmaf(xl, LOG2E, -ce_max)) * ce_scale;
                 else cls = focal_cost<MODE == 1>(xl, prm.focal_alpha, prm.focal_gamma);
                 return pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
             };
@@ -503,7 +528,7 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     // tile kernel: LDS = staged targets + softmax partials (softmax variant) + the logit tile
     const int mode = params->cls_mode == 0 ? 0 : (params->focal_gamma == 2.0f ? 1 : 2);
     const int tile_waves = g_tile_waves == 8 ? 8 : 4;
-    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 8 * sizeof(float) : 0) +
+    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 16 * sizeof(float) : 0) +
                             (size_t)64 * C * sizeof(float);
     if (tile && tile_lds > 160 * 1024) return DM_E_UNSUPPORTED;
     typedef void (*TileFn)(const DmSetArray, const int, const int, const int, const int64_t *, const float *,
