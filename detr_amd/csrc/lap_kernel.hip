@@ -35,6 +35,8 @@ namespace {
 constexpr double INF = __builtin_huge_val();
 constexpr int FAST_MAX_NCOL = 17;
 constexpr int FAST_MAX_Q = 64 * FAST_MAX_NCOL;
+constexpr int BLOCK_MAX_NCOL_WIDE = 4;                 // lap_block_kernel<NCOL <= 4> may use 1024 threads ...
+constexpr int BLOCK_MAX_Q = 1024 * BLOCK_MAX_NCOL_WIDE;   // ... and then takes up to 4096 columns
 constexpr int GENERIC_MAX = 4096;
 
 int g_lap_wave_budget = 0;   // 0: automatic (12288); otherwise wavefronts a launch of lap_block_kernel may ask for
@@ -431,7 +433,8 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(bool cand, unsig
     return at;
 }
 
-// One workgroup of W wavefronts (W = blockDim.x / 64, 1..16) per problem with T < Q <= 64*W*NCOL.
+// One workgroup of W wavefronts (W = blockDim.x / 64, 1..16) per problem with T < Q <= 64*W*NCOL
+// (up to 4096 columns with 16 wavefronts and 4 columns per thread).
 // Thread `tid` owns the columns (queries) j = tid + 64*W*k, k < NCOL, and keeps their reduced
 // cost, dual, assignment, predecessor and list position in registers; scanned columns are
 // parked (reduced cost +inf, dual -inf) as in lap_wave_kernel.  Per Dijkstra step every wave
@@ -441,8 +444,9 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(bool cand, unsig
 // records are double-buffered by step parity).  State that every wave needs (list, row
 // assignment of a one-step row) is written redundantly by each wave, so a wave only ever
 // depends on its own LDS writes between barriers.
-template <int NCOL>
-__global__ __launch_bounds__(NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL)) void lap_block_kernel(const DmSetArray sets, const int S,
+// WIDE: compiled for up to 1024 threads whatever NCOL (the register budget of 16 wavefronts).
+template <int NCOL, bool WIDE>
+__global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL)) void lap_block_kernel(const DmSetArray sets, const int S,
                                                          const float *__restrict__ cost,
                                                          const int32_t *__restrict__ tgt_off,
                                                          const int32_t *__restrict__ order,
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
                                                           const int32_t *__restrict__ order,
                                                           int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
                                                           int32_t *status, const int c_cap, const int r_cap,
-                                                          const int all_problems)
+                                                          const int all_problems, const int fast_max_q)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
     const int T = tgt_off[b + 1] - t0;
     if (T == 0) return;
     const bool transposed = T < Q;        // scipy transposes when the matrix has more rows (queries) than columns
-    if (!all_problems && transposed && Q <= FAST_MAX_Q) return;   // lap_wave_kernel's problem
+    if (!all_problems && transposed && Q <= fast_max_q) return;   // a register kernel's problem
     const int nr = transposed ? T : Q;
     const int nc = transposed ? Q : T;
 
@@ -939,16 +943,22 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
     // the attribute belongs to the function on ONE device: remember per device where it is set
-    static unsigned long long big_lds_devices = 0;
+    // shapes beyond the narrow variant's thread limit use the variant compiled for 1024 threads
+    constexpr int narrow_threads = NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL);
+    const bool wide = 64 * waves > narrow_threads;
+    if (wide && NCOL > BLOCK_MAX_NCOL_WIDE) return DM_E_UNSUPPORTED;
+    auto kernel = wide ? lap_block_kernel<NCOL, (NCOL <= BLOCK_MAX_NCOL_WIDE)> : lap_block_kernel<NCOL, false>;
+    static unsigned long long big_lds_devices[2] = {0, 0};
     int dev = 0;
-    if (fixed + want > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !(dev < 64 && ((big_lds_devices >> dev) & 1ull))) {
-        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_block_kernel<NCOL>),
+    if (fixed + want > 64 * 1024 && hipGetDevice(&dev) == hipSuccess &&
+        !(dev < 64 && ((big_lds_devices[wide] >> dev) & 1ull))) {
+        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
                                "hipFuncSetAttribute(lap_block_kernel)");
         if (rc != DM_OK) return rc;
-        if (dev < 64) big_lds_devices |= 1ull << dev;
+        if (dev < 64) big_lds_devices[wide] |= 1ull << dev;
     }
-    hipLaunchKernelGGL(lap_block_kernel<NCOL>, dim3((unsigned)n * B), dim3(64 * waves), fixed + want, st, arr, n,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n * B), dim3(64 * waves), fixed + want, st, arr, n,
                        cost, tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
     return dm::check_hip(hipGetLastError(), "lap_block_kernel launch");
 }
@@ -1003,10 +1013,27 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
     if (!sets || !cost || !tgt_off || !src_out || !tgt_out) return DM_E_INVALID_ARG;
     if (S > 4096) return DM_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // Sets wider than the wavefront kernel's 1088 columns (up to 4096) go to the workgroup kernel when
+    // it may use its widest shapes for them (16 wavefronts x at most 4 columns per thread, state
+    // within the LDS budget); otherwise the list-order kernel takes them as before.
+    int fast_max_q = FAST_MAX_Q;
+    if ((g_lap_mode == 0 || g_lap_mode == 2) && max_T <= 1024) {
+        int wide = 0, widest = 0;
+        for (int s = 0; s < S; ++s)
+            if (sets[s].Q > FAST_MAX_Q && sets[s].Q <= BLOCK_MAX_Q && max_T < sets[s].Q) {
+                ++wide;
+                widest = std::max(widest, sets[s].Q);
+            }
+        if (wide > 0) {
+            int ncol = 0, waves = 0;
+            pick_shape(widest, (long long)wide * B, &ncol, &waves);
+            if (ncol <= BLOCK_MAX_NCOL_WIDE) fast_max_q = BLOCK_MAX_Q;
+        }
+    }
     for (int s = 0; s < S; ++s) {
         const int Q = sets[s].Q;
         if (Q < 1 || sets[s].q_stride < Q) return DM_E_INVALID_ARG;
-        const bool needs_generic = (g_lap_mode == 1) || Q > FAST_MAX_Q || max_T >= Q;
+        const bool needs_generic = (g_lap_mode == 1) || Q > fast_max_q || max_T >= Q;
         if (needs_generic && (Q > GENERIC_MAX || max_T > GENERIC_MAX)) return DM_E_UNSUPPORTED;
     }
 
@@ -1018,9 +1045,9 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
         // behind each other.
         int max_Q = 0, count = 0, distinct = 0;
         for (int s = 0; s < S; ++s) {
-            if (sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q) continue;
+            if (sets[s].Q > fast_max_q || max_T >= sets[s].Q) continue;
             bool seen = false;
-            for (int r = 0; r < s; ++r) seen |= sets[r].Q == sets[s].Q && !(sets[r].Q > FAST_MAX_Q || max_T >= sets[r].Q);
+            for (int r = 0; r < s; ++r) seen |= sets[r].Q == sets[s].Q && !(sets[r].Q > fast_max_q || max_T >= sets[r].Q);
             distinct += seen ? 0 : 1;
             max_Q = std::max(max_Q, sets[s].Q);
             ++count;
@@ -1029,11 +1056,12 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
         int ncol = 1, waves = 1;
         if (distinct > 1) pick_shape(max_Q, P, &ncol, &waves);
         // ... as long as all workgroups are resident at once (8192 wavefront slots on the chip)
-        if (distinct > 1 && count <= DM_MAX_SETS_PER_LAUNCH && P * waves <= 8192) {
+        if (distinct > 1 && count <= DM_MAX_SETS_PER_LAUNCH && P * waves <= 8192 &&
+            (max_Q <= FAST_MAX_Q || ncol <= BLOCK_MAX_NCOL_WIDE)) {
             DmSetArray arr;
             int n = 0, max_stride = max_Q;
             for (int s = 0; s < S; ++s) {
-                if (sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q) continue;
+                if (sets[s].Q > fast_max_q || max_T >= sets[s].Q) continue;
                 arr.s[n++] = sets[s];
                 done[s] = true;
                 max_stride = std::max(max_stride, sets[s].q_stride);
@@ -1047,7 +1075,7 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
         // one launch per distinct Q among the (remaining) sets the register kernel can take
         for (int s0 = 0; s0 < S; ++s0) {
             const int Q = sets[s0].Q;
-            if (done[s0] || Q > FAST_MAX_Q) continue;
+            if (done[s0] || Q > fast_max_q) continue;
             int total = 0;
             for (int s = s0; s < S; ++s) total += (!done[s] && sets[s].Q == Q) ? 1 : 0;
             // few problems: a workgroup of several wavefronts per problem (latency); many: one
@@ -1057,7 +1085,8 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
             // crossover measured at Q=600, T~16: 20480 column slices; problems with many rows (T up to
             // 100 at Q=900) stay faster in the workgroup kernel well beyond that
             const long long slices = P * ((Q + 63) / 64);
-            const bool use_block = g_lap_mode == 2 || (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 20480));
+            const bool use_block = g_lap_mode == 2 || Q > FAST_MAX_Q ||
+                                   (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 20480));
             if (use_block) pick_shape(Q, P, &ncol, &waves);
             DmSetArray arr;
             int n = 0, max_stride = Q;
@@ -1085,7 +1114,7 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
     DmSetArray arr;
     int n = 0, max_Q = 0;
     for (int s = 0; s <= S; ++s) {
-        if (s < S && ((g_lap_mode == 1) || sets[s].Q > FAST_MAX_Q || max_T >= sets[s].Q)) {
+        if (s < S && ((g_lap_mode == 1) || sets[s].Q > fast_max_q || max_T >= sets[s].Q)) {
             arr.s[n++] = sets[s];
             if (sets[s].Q > max_Q) max_Q = sets[s].Q;
         }
@@ -1103,7 +1132,7 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
                 if (rc != DM_OK) return rc;
             }
             hipLaunchKernelGGL(lap_generic_kernel, dim3((unsigned)n * B), dim3(64), lds, st, arr, n, cost, tgt_off,
-                               order, src_out, tgt_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0);
+                               order, src_out, tgt_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0, fast_max_q);
             int rc = dm::check_hip(hipGetLastError(), "lap_generic_kernel launch");
             if (rc != DM_OK) return rc;
             n = 0; max_Q = 0;

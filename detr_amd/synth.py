@@ -38,6 +38,9 @@ WORKLOADS = {
     # DINO with the first stage over all H*W encoder tokens (25 x 42)
     "cfg3_hw": Workload("cfg3_hw", 64, [300] * 6 + [1050], 2, 2, "focal", "poisson16",
                         dict(cls_loss="focal", **_W), 3500),
+    # the same with a larger image: 50 x 42 encoder tokens, beyond the 1088 columns of the one-wavefront kernel
+    "cfg3_hw2": Workload("cfg3_hw2", 64, [300] * 6 + [2100], 2, 2, "focal", "poisson16",
+                         dict(cls_loss="focal", **_W), 3600),
     # COCO-like stress
     "cfg4": Workload("cfg4", 256, [900] * 6, 91, 91, "focal", "heavy_tail", dict(cls_loss="focal", **_W), 4000),
     # Co-DETR scale: 6 layers x 2 heads

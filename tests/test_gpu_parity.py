@@ -97,9 +97,12 @@ def _lsap_matrices(rng):
         t = q + int(rng.integers(0, 40))
         mats.append(rng.integers(0, 4, (q, t)).astype(np.float32))
     for shape in [(1, 1), (9, 1), (1, 9), (7, 7), (64, 5), (65, 64), (128, 127), (129, 3), (1088, 17), (1089, 5),
-                  (1500, 30), (320, 100), (321, 100), (640, 2), (641, 2)]:
+                  (1500, 30), (320, 100), (321, 100), (640, 2), (641, 2), (2048, 40), (2049, 7), (3072, 25),
+                  (4096, 12)]:
         mats.append(np.zeros(shape, dtype=np.float32))
         mats.append(rng.standard_normal(shape).astype(np.float32))
+    mats.append(rng.integers(0, 3, (2500, 20)).astype(np.float32))     # heavy ties beyond 1088 columns
+    mats.append(np.round(rng.random((4000, 15)), 1).astype(np.float32))
     m = rng.random((60, 9)).astype(np.float32)
     m[:, 2] = np.inf
     m[4, 2] = 0.25
@@ -200,6 +203,12 @@ def test_workload_cfg2_full():
 
 def test_workload_cfg3_first_stage_hw():
     exact, total = _check_workload("cfg3_hw", batch=16)
+    assert exact >= 0.99 * total
+
+
+def test_workload_cfg3_wide_first_stage():
+    """First stage over 2100 encoder tokens: beyond the one-wavefront kernel's 1088 columns."""
+    exact, total = _check_workload("cfg3_hw2", batch=8)
     assert exact >= 0.99 * total
 
 
