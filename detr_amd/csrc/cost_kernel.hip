@@ -354,28 +354,28 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
 
     const float *xr = tile + lane * C;
     constexpr float LOG2E = 1.44269504088896f;
-    float ce_max = 0.0f, ce_scale = 1.0f;      // softmax in base 2: p = exp2(x * LOG2E - ce_max) * (-ce_scale)
+    float ce_max = 0.0f, ce_scale = 1.0f;      // class cost -softmax = exp2((x - ce_max) * LOG2E) * ce_scale
     if (MODE == 0) {
         // Softmax statistics of the lane's row in ONE pass over the tile.  The walk over the row is
         // k -> column (k + rot) mod C, rot = lane for even C (bank spreading), 0 otherwise.  The walk
         // positions form 16 residue classes (mod 16); a wavefront runs its 16 / W classes as
         // independent chains side by side.  A chain keeps a running maximum m and the sum s of
-        // exp2(t - m), rescaled when m grows (one exponential per element either way).  Chains c and
+        // exp(x - m), rescaled when m grows (one exponential per element either way).  Chains c and
         // c + 8 always sit in the same wavefront and are merged there; the 8 merged pairs meet in LDS
         // and are merged in a fixed order, so the result does not depend on the number of wavefronts.
         constexpr int NCH = 16 / W;
-        const int rot = (C & 1) ? 0 : lane;
+        const int rot = (C & 1) ? 0 : lane % C;     // (C may be smaller than the wavefront)
         float m[NCH], sum[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) { m[i] = -3.0e38f; sum[i] = 0.0f; }   // finite start: a -inf logit adds 0
         auto take = [&](int i, int k) {
             int c = k + rot;
             c = c >= C ? c - C : c;
-            const float t = xr[c] * LOG2E;
-            const float d = t - m[i];
-            const float e = __builtin_amdgcn_exp2f(-fabsf(d));
+            const float x = xr[c];
+            const float d = x - m[i];        // subtract first: exact for nearby logits however large they are
+            const float e = __builtin_amdgcn_exp2f(-fabsf(d) * LOG2E);
             sum[i] = d > 0.0f ? __builtin_fmaf(sum[i], e, 1.0f) : sum[i] + e;
-            m[i] = fmaxf(m[i], t);
+            m[i] = fmaxf(m[i], x);
         };
         int k0 = 0;
         for (; k0 + 16 <= C; k0 += 16) {
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
         for (int i = 0; i < NCH / 2; ++i) {       // classes wave + W*i and wave + W*i + 8
             const int j = i + NCH / 2;
             const float mm = fmaxf(m[i], m[j]);
-            const float s2 = __builtin_fmaf(sum[i], __builtin_amdgcn_exp2f(m[i] - mm),
-                                            sum[j] * __builtin_amdgcn_exp2f(m[j] - mm));
+            const float s2 = __builtin_fmaf(sum[i], __builtin_amdgcn_exp2f((m[i] - mm) * LOG2E),
+                                            sum[j] * __builtin_amdgcn_exp2f((m[j] - mm) * LOG2E));
             part[(wave + W * i) * 64 + lane] = mm;
             part[(8 + wave + W * i) * 64 + lane] = s2;
         }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
 #pragma unroll
         for (int r = 1; r < 8; ++r) mx = fmaxf(mx, ms[r]);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ss[r] *= __builtin_amdgcn_exp2f(ms[r] - mx);
+        for (int r = 0; r < 8; ++r) ss[r] *= __builtin_amdgcn_exp2f((ms[r] - mx) * LOG2E);
 #pragma unroll
         for (int h = 4; h >= 1; h /= 2)
 #pragma unroll
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
                 const TgtRec g = tg[i];
                 const float xl = xr[g.label];
                 float cls;
-                if (MODE == 0) cls = __builtin_amdgcn_exp2f(__builtin_fmaf(xl, LOG2E, -ce_max)) * ce_scale;
+                if (MODE == 0) cls = __builtin_amdgcn_exp2f((xl - ce_max) * LOG2E) * ce_scale;
                 else cls = focal_cost<MODE == 1>(xl, prm.focal_alpha, prm.focal_gamma);
                 return pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
             };

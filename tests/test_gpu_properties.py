@@ -131,3 +131,28 @@ def test_matcher_survives_deepcopy_and_pickle_after_use():
         got = clone(outputs, targets)
         for (a0, a1), (b0, b1) in zip(base, got):
             assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+@pytest.mark.parametrize("cls_loss,C,gamma", [("focal", 2, 2.0), ("focal", 7, 1.5), ("ce", 3, 2.0), ("ce", 12, 2.0)])
+def test_extreme_logits_match_the_oracle(cls_loss, C, gamma):
+    """Saturated sigmoids / softmaxes (logits up to +-90) stay finite and agree with the CPU restatement."""
+    import detr_amd
+    from oracle import oracle
+
+    rng = np.random.default_rng(17)
+    B, Q, sizes = 3, 70, [5, 9, 2]
+    logits = rng.choice(np.array([-90.0, -30.0, -8.0, 0.0, 8.0, 30.0, 90.0], np.float32), size=(B, Q, C))
+    logits += rng.standard_normal((B, Q, C)).astype(np.float32) * 0.01
+    boxes = np.stack([_boxes(rng, Q) for _ in range(B)])
+    labels = [rng.integers(0, C - (cls_loss == "ce"), t) for t in sizes]
+    tboxes = [_boxes(rng, t) for t in sizes]
+    kw = dict(cls_loss=cls_loss, cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, focal_alpha=0.25, focal_gamma=gamma)
+    ref, ref_cost = oracle.match(logits, boxes, labels, tboxes, return_cost=True, **kw)
+    outputs = {"pred_logits": torch.from_numpy(logits).cuda(), "pred_boxes": torch.from_numpy(boxes).cuda()}
+    targets = [{"labels": torch.from_numpy(np.asarray(l, np.int64)).cuda(), "boxes": torch.from_numpy(b).cuda()}
+               for l, b in zip(labels, tboxes)]
+    blocks = detr_amd.HungarianMatcher(**kw).cost_blocks(outputs, targets)
+    for b in range(B):
+        got = blocks[b].cpu().numpy()
+        assert np.isfinite(got).all()
+        golden_io.assert_cost_close(got, ref_cost[b], logits[b], labels[b], cls_loss, 2.0, 0.25, gamma)
