@@ -21,7 +21,7 @@ def _boxes(rng, n):
 def problems(draw):
     B = draw(st.integers(1, 5))
     Q = draw(st.sampled_from([1, 2, 5, 17, 63, 64, 65, 100, 130, 257]))
-    C = draw(st.sampled_from([1, 2, 3, 4, 5, 8, 11, 80, 91]))
+    C = draw(st.sampled_from([1, 2, 3, 4, 5, 6, 8, 11, 12, 20, 32, 33, 64, 80, 91, 92, 128]))
     sizes = [draw(st.sampled_from([0, 0, 1, 2, 3, 7, 16, 40, 70])) for _ in range(B)]
     cls = draw(st.sampled_from(["ce", "focal"]))
     w = (draw(st.sampled_from([0.0, 1.0, 2.0])), draw(st.sampled_from([0.0, 1.0, 5.0])),
@@ -32,7 +32,7 @@ def problems(draw):
     return B, Q, C, sizes, cls, w, seed
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@settings(max_examples=150, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
 @given(problems())
 def test_random_problems_match_oracle_and_scipy(p):
     import detr_amd
