@@ -1,0 +1,29 @@
+"""bench.py prints ONE JSON line with the agreed keys (short run, no CPU baseline)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_json_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, check=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in rec, key
+    assert rec["steps"] == 5 and rec["warmup"] == 2 and rec["n_gpus"] == 1 and rec["unit"] == "images/s"
+    assert rec["value"] > 0 and rec["higher_is_better"] is True and rec["vs_baseline"] is None
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    roof = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0 < rec["roofline_stress"]["frac"] < 1.0
