@@ -156,3 +156,28 @@ def test_extreme_logits_match_the_oracle(cls_loss, C, gamma):
         got = blocks[b].cpu().numpy()
         assert np.isfinite(got).all()
         golden_io.assert_cost_close(got, ref_cost[b], logits[b], labels[b], cls_loss, 2.0, 0.25, gamma)
+
+
+def test_more_output_sets_than_one_launch_takes():
+    """20 output sets (a launch carries at most 16 by value), mixed Q: same result as set-by-set calls;
+    the fused consumers agree with the torch expressions on every one of them."""
+    import detr_amd
+    from detr_amd import losses, synth
+
+    gen = torch.Generator().manual_seed(5)
+    _, _, targets = synth.make_workload("cfg1", device="cuda", batch=3)
+    sets = []
+    for s in range(20):
+        q = [40, 75, 130][s % 3]
+        sets.append(synth.make_output_set(3, q, 3, gen, device="cuda"))
+    matcher = detr_amd.HungarianMatcher("ce", 2.0, 5.0, 2.0)
+    many = matcher.match_many(sets, targets)
+    flats = matcher.match_flat(sets, targets)
+    maps = losses.target_class_maps(flats, 2)
+    assert len(many) == 20
+    for s, out in enumerate(sets):
+        single = matcher(out, targets)
+        for (a0, a1), (b0, b1) in zip(single, many[s]):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+        assert torch.equal(flats[s].src_idx.cpu(), torch.cat([i for i, _ in single]))
+        assert torch.equal(maps[s], flats[s].target_classes(2))
