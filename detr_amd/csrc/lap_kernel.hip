@@ -548,6 +548,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     st_c1 = __builtin_amdgcn_s_memtime();
 #endif
     int par = 0;
+    unsigned scanned = 0;      // bit k: this thread's column k has been scanned (parked) in the current row
     for (int cur = 0; cur < nr; ++cur) {
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
@@ -636,6 +637,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 if (j == jw) {       // park the column in its owner's registers
                     spc_real[k] = spc[k]; v_real[k] = v[k];
                     spc[k] = INF; v[k] = NEG_INF;
+                    scanned |= 1u << k;
                 }
             }
             par ^= 1;
@@ -665,6 +667,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 posr[k] = nc - 1 - j;
                 spc[k] = INF;
             }
+            scanned = 0;
             if (lane == 0) {
                 u[cur] = min_val;                     // it was 0
                 col4row[cur] = sink;
@@ -674,7 +677,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         } else {
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                if (v[k] == NEG_INF && tid + BS * k < nc) {      // a column scanned in this row
+                if ((scanned >> k) & 1u) {      // a column scanned in this row
                     const int j = tid + BS * k;
                     const double d = min_val - spc_real[k];
                     if (j != sink) u[r4c[k]] += d;
@@ -696,15 +699,17 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 }
             }
             __syncthreads();
-            // refresh the assignments of the scanned columns; list and positions back to initial
-            for (int e = 0; e < nsc; ++e) {
-                const int j = __builtin_amdgcn_readfirstlane(sclist[e]);
-                const int r = __builtin_amdgcn_readfirstlane(row4col[j]);
+            // refresh the assignments of the scanned columns (every owner for its own columns, in
+            // parallel); list and positions back to initial
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k)
-                    if (tid + BS * k == j) r4c[k] = r;
-                if (lane == 0) remaining[nc - 1 - j] = j;
+            for (int k = 0; k < NCOL; ++k) {
+                if ((scanned >> k) & 1u) {
+                    const int j = tid + BS * k;
+                    r4c[k] = row4col[j];
+                    remaining[nc - 1 - j] = j;
+                }
             }
+            scanned = 0;
             for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
