@@ -478,8 +478,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     uint4 *rec = reinterpret_cast<uint4 *>(u + t_cap);      // [2][16] published candidates: hi, lo, key, column
     int *recr = reinterpret_cast<int *>(rec + 32);          // [2][16] row assigned to that column, or -1
     int *col4row = recr + 32;                               // [t_cap]
-    int *sclist = col4row + t_cap;                          // [t_cap] columns scanned in the current row, in order
-    int *row4col = sclist + t_cap;                          // [QCAP]
+    int *row4col = col4row + t_cap;                         // [QCAP]
     int *pathL = row4col + QCAP;                            // [QCAP]
     int *remaining = pathL + QCAP;                          // [QCAP] list position -> column
     float *crow = reinterpret_cast<float *>(remaining + QCAP);   // [lds_cost_floats] first rows of the block
@@ -625,10 +624,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             const int pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
             // swap-with-last removal of column jw (every wave writes the same values)
             const int jl = __builtin_amdgcn_readfirstlane(jl_read);
-            if (lane == 0) {
-                remaining[pw] = jl;
-                sclist[nc - n] = jw;
-            }
+            if (lane == 0) remaining[pw] = jl;
             --n;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
@@ -713,7 +709,9 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
-            __syncthreads();
+            // No barrier here: before the barrier of the next row's first step a wave reads only u[cur + 1]
+            // (untouched so far), cost rows and the last list slot, which it restores itself.
+            if (lane == 0) remaining[nc - 1] = 0;
         }
     }
 
@@ -938,7 +936,7 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const int qcap = 64 * waves * NCOL;
-    const size_t fixed = (size_t)t_cap * (8 + 4 + 4) + 32 * (16 + 4) + (size_t)3 * qcap * 4;
+    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * (16 + 4) + (size_t)3 * qcap * 4;
     size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS and keep their cost rows in
     // it; many: more resident workgroups beat resident rows
