@@ -76,3 +76,29 @@ def test_matcher_refuses_cpu_tensors():
         m(out, tg)
     with pytest.raises(AssertionError):
         detr_amd.HungarianMatcher("ce", 0, 0, 0)
+
+
+def test_index_set_layout_and_consumer_argument_validation():
+    import detr_amd
+    from detr_amd._lib import DmIndexSet
+
+    assert ctypes.sizeof(DmIndexSet) == 40      # 3 pointers, 1 int64, 2 int32
+    assert DmIndexSet.out_off.offset == 24 and DmIndexSet.Q.offset == 32
+    lib = detr_amd.lib
+    sets = (DmIndexSet * 1)()
+    assert lib.dm_pair_loss_f32(sets, -1, 1, 0, None, None, None, None, None, None, None) == -1
+    assert lib.dm_pair_loss_f32(sets, 1, 1, 0, None, None, None, None, None, None, None) == -1     # Q = 0
+    assert lib.dm_target_classes_i64(sets, 0, 1, 0, None, None, None, None, 0, None) == 0          # nothing to do
+    assert lib.dm_atss_f32(sets, 0, 1, 0, 65, None, None, None, None, None) == -3                  # k beyond 64
+    assert lib.dm_frcnn_f32(sets, 0, 0, 0, 1, 0.7, 0.3, None, None, None, None, None, None) == 0
+
+
+def test_knobs_reject_values_they_do_not_know():
+    import detr_amd
+
+    lib = detr_amd.lib
+    assert lib.dm_debug_set_knob(99, 1) == -1
+    assert lib.dm_debug_set_knob(detr_amd._lib.KNOBS["tile_waves"], 5) == -1
+    assert lib.dm_debug_set_knob(detr_amd._lib.KNOBS["cost_tsplit"], 3) == -1
+    for name in detr_amd._lib.KNOBS:
+        detr_amd._lib.set_knob(name, 0)
