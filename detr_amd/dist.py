@@ -28,6 +28,19 @@ def shard_range(n_images: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def balanced_shards(target_sizes: Sequence[int], world_size: int) -> List[List[int]]:
+    """Image indices per rank when the caller controls placement: images sorted by target count,
+    dealt to the ranks in boustrophedon order (0..G-1, G-1..0, ...), so every rank gets the same
+    number of images (+-1) and nearly the same number of targets -- the assignment kernel's time on
+    a rank is set by its heaviest images."""
+    order = sorted(range(len(target_sizes)), key=lambda i: (-int(target_sizes[i]), i))
+    shards = [[] for _ in range(world_size)]
+    for pos, img in enumerate(order):
+        lap, k = divmod(pos, world_size)
+        shards[k if lap % 2 == 0 else world_size - 1 - k].append(img)
+    return [sorted(s) for s in shards]
+
+
 def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> torch.Tensor:
     """[S] float32 tensor on ``device``: clamp(sum over ranks / world_size, min=1).
 

@@ -115,3 +115,21 @@ def test_num_boxes_all_reduce_world_size_2():
     expect = [max(c / world, 1.0) for c in matched_box_counts(sizes, [600] * 6 + [10])]
     assert got[0] == got[1]
     np.testing.assert_allclose(got[0], expect, rtol=1e-6)
+
+
+def test_balanced_shards_even_out_images_and_targets():
+    from detr_amd import synth
+    from detr_amd.dist import balanced_shards
+
+    rng = np.random.default_rng(4)
+    sizes = synth.target_counts("heavy_tail", 256, rng).tolist()
+    for world in (1, 2, 4, 8):
+        shards = balanced_shards(sizes, world)
+        assert sorted(i for s in shards for i in s) == list(range(256))
+        counts = [len(s) for s in shards]
+        assert max(counts) - min(counts) <= 1
+        loads = [sum(sizes[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(sizes)          # within one heaviest image of each other
+        contiguous = [sum(sizes[r * 256 // world:(r + 1) * 256 // world]) for r in range(world)]
+        assert max(loads) - min(loads) <= max(contiguous) - min(contiguous) or world == 1
+    assert balanced_shards([], 4) == [[], [], [], []]
