@@ -137,7 +137,7 @@ class FasterRCNN(torch.nn.Module):
         _lib.check(rc, "dm_frcnn_f32")
         host = _to_host(buf)
         words = host[:n_pos].view(np.uint64).reshape(S, M, W)
-        neg = np.unpackbits(host[n_pos:n_pos + n_neg].view(np.uint8), bitorder="little").reshape(S, B, W * 64)
+        neg = np.unpackbits(host[n_pos:n_pos + n_neg].view(np.uint8), bitorder="little").view(np.bool_).reshape(S, B, W * 64)
         best = host[n_pos + n_neg:].view(np.int32)[:S * M].reshape(S, M)
         # positives are sparse: expand only the non-zero words, add the best prediction of every
         # target (:90), then sort by (set, target, prediction) and drop the duplicates
