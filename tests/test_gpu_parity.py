@@ -265,6 +265,36 @@ def test_cost_kernel_shape_knobs_do_not_change_the_cost(name):
             detr_amd._lib.set_knob(knob, 0)
 
 
+def test_many_problems_wavefront_kernel_without_resident_rows():
+    """More than 512 problems: the one-wavefront kernel keeps only its state in LDS and reads the cost
+    rows from memory.  Same pairs as the workgroup kernel on every problem, scipy on a sample."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg5", device="cuda", batch=64)      # 12 sets x 64 images = 768 problems
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    base, costs = matcher.match_many(sets, targets, return_cost=True)
+    detr_amd._lib.set_knob("lap_kernel", 3)
+    try:
+        wave = matcher.match_many(sets, targets)
+    finally:
+        detr_amd._lib.set_knob("lap_kernel", 0)
+    for s in range(len(sets)):
+        for (a0, a1), (b0, b1) in zip(base[s], wave[s]):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    sizes = [len(t["labels"]) for t in targets]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    rng = np.random.default_rng(1)
+    for s in rng.choice(len(sets), 3, replace=False):
+        cost_s = costs[s].cpu().numpy()
+        for b in rng.choice(64, 8, replace=False):
+            if sizes[b] == 0:
+                continue
+            rs, cs = linear_sum_assignment(cost_s[off[b]:off[b + 1]].T)
+            np.testing.assert_array_equal(wave[s][b][0].numpy(), rs)
+            np.testing.assert_array_equal(wave[s][b][1].numpy(), cs)
+
+
 def test_image_order_invariance():
     import detr_amd
     from detr_amd import synth
