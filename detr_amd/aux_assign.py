@@ -157,6 +157,37 @@ class FasterRCNN(torch.nn.Module):
             result.append((pos[s], neg_indices))
         return result
 
+    @torch.no_grad()
+    def dense_class_targets(self, outputs_list, targets, n_cls: int) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        """`(maps, num_pos)`: the `[B, Q]` int64 class targets of every output set as
+        `calc_cls_loss_with_ignore` builds them from `forward`'s lists (co_detr/loss.py:153-159) --
+        `n_cls` for negatives, the label of the last positive target otherwise, -1 for ignored
+        predictions -- and the int32 `[S]` number of positive pairs per set (loss.py:151).
+        Everything stays on the device: no index lists, no host copy, no synchronisation."""
+        device, packed, sets, keep = _prepare(outputs_list, targets)
+        S, B, M = len(outputs_list), packed.batch, packed.total
+        queries = [int(b.shape[1]) for b in keep]
+        W = (max(queries) + 63) // 64
+        maps = [torch.empty(B, q, dtype=torch.int64, device=device) for q in queries]
+        for i, m_ in enumerate(maps):
+            sets[i].target_cls = m_.data_ptr()
+        # one int64 buffer: [pos_bits u64 S*M*W | neg_bits u64 S*B*W | best int32 S*M (padded) | num_pos int32 S]
+        n_pos, n_neg, n_best = S * M * W, S * B * W, (S * M + 1) // 2
+        buf = torch.empty(n_pos + n_neg + n_best + (S + 1) // 2, dtype=torch.int64, device=device)
+        best_ptr = buf.data_ptr() + 8 * (n_pos + n_neg)
+        num_pos = buf[n_pos + n_neg + n_best:].view(torch.int32)[:S]
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            rc = lib.dm_frcnn_f32(sets, S, B, M, W, float(self.pos_threshold), float(self.neg_threshold),
+                                  packed.boxes.data_ptr(), packed.offsets_ptr, buf.data_ptr(), best_ptr,
+                                  buf.data_ptr() + 8 * n_pos, stream)
+            _lib.check(rc, "dm_frcnn_f32")
+            rc = lib.dm_frcnn_dense_i64(sets, S, B, M, float(self.pos_threshold), float(self.neg_threshold),
+                                        packed.boxes.data_ptr(), packed.labels.data_ptr(), packed.offsets_ptr,
+                                        best_ptr, int(n_cls), num_pos.data_ptr(), stream)
+        _lib.check(rc, "dm_frcnn_dense_i64")
+        return maps, num_pos
+
 
 def get_aux_heads(args):
     """As the reference's factory (auxiliary_head.py:7-15)."""

@@ -169,6 +169,50 @@ __global__ __launch_bounds__(64) void rcnn_neg_kernel(const DmIndexSetArray sets
     if (lane == 0) neg_bits[((size_t)blockIdx.z * B + b) * W + w] = bits;
 }
 
+// Faster-RCNN dense class targets, one wavefront per (set, image, 64 predictions): the [B, Q] map
+// that the reference's calc_cls_loss_with_ignore builds from the positive pairs and the negative
+// list (/root/reference/models/co_detr/loss.py:153-159), without materialising either list:
+//   negative (best IoU < neg_threshold, or an image without targets)  -> n_cls
+//   else positive for at least one target (IoU > pos_threshold, or the target's best prediction)
+//        -> that target's label; the LAST such target wins, as the reference's CPU scatter does
+//   else ignored                                                        -> -1
+// `best` comes from rcnn_pos_kernel.  num_pos[set] (optional, zeroed by the caller) receives the number
+// of positive (prediction, target) pairs, the reference's normaliser (loss.py:151).
+__global__ __launch_bounds__(64) void rcnn_dense_kernel(const DmIndexSetArray sets, const int B, const int M,
+                                                        const float pos_threshold, const float neg_threshold,
+                                                        const float *__restrict__ tgt_boxes,
+                                                        const int64_t *__restrict__ tgt_labels,
+                                                        const int32_t *__restrict__ tgt_off,
+                                                        const int32_t *__restrict__ best, const int64_t n_cls,
+                                                        int32_t *__restrict__ num_pos)
+{
+    const DmIndexSet &set = sets.s[blockIdx.z];
+    const int b = blockIdx.y, lane = threadIdx.x, Q = set.Q;
+    const int q = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= Q) return;                     // whole wavefront past the end of a shorter set
+    const int first = tgt_off[b], T = tgt_off[b + 1] - first;
+    int64_t value = n_cls;
+    int pairs = 0;
+    if (q < Q && T > 0) {
+        const Corners p = corners(reinterpret_cast<const float4 *>(set.pred_boxes)[(size_t)b * Q + q]);
+        const int32_t *bst = best + (size_t)blockIdx.z * M + first;
+        float top = -__builtin_huge_valf();
+        int winner = -1;
+        for (int t = 0; t < T; ++t) {
+            const float iou = iou_of(corners(reinterpret_cast<const float4 *>(tgt_boxes)[first + t]), p);
+            top = fmaxf(top, iou);
+            if (iou > pos_threshold || bst[t] == q) { winner = t; ++pairs; }
+        }
+        if (!(top < neg_threshold)) value = winner >= 0 ? tgt_labels[first + winner] : (int64_t)-1;
+    }
+    if (q < Q) set.target_cls[(size_t)b * Q + q] = value;
+    if (num_pos) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) pairs += __shfl_xor(pairs, off);
+        if (lane == 0 && pairs) atomicAdd(num_pos + blockIdx.z, pairs);
+    }
+}
+
 int check_sets(const DmIndexSet *sets, int S, int B, int M)
 {
     if (S < 0 || B < 0 || M < 0 || (S > 0 && !sets)) return DM_E_INVALID_ARG;
@@ -233,6 +277,39 @@ extern "C" int dm_frcnn_f32(const DmIndexSet *sets, int S, int B, int M, int W, 
         hipLaunchKernelGGL(rcnn_neg_kernel, dim3(W, B, n), dim3(64), 0, st, arr, B, W, neg_threshold, tgt_boxes, tgt_off,
                            reinterpret_cast<unsigned long long *>(neg_bits) + (size_t)s0 * B * W);
         rc = dm::check_hip(hipGetLastError(), "rcnn_neg_kernel launch");
+        if (rc != DM_OK) return rc;
+    }
+    return DM_OK;
+}
+
+extern "C" int dm_frcnn_dense_i64(const DmIndexSet *sets, int S, int B, int M, float pos_threshold,
+                                  float neg_threshold, const float *tgt_boxes, const int64_t *tgt_labels,
+                                  const int32_t *tgt_off, const int32_t *best, int64_t n_cls, int32_t *num_pos,
+                                  void *stream)
+{
+    int rc = check_sets(sets, S, B, M);
+    if (rc != DM_OK) return rc;
+    if (S == 0) return DM_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (num_pos) {
+        rc = dm::check_hip(hipMemsetAsync(num_pos, 0, sizeof(int32_t) * (size_t)S, st), "hipMemsetAsync(num_pos)");
+        if (rc != DM_OK) return rc;
+    }
+    if (B == 0) return DM_OK;
+    if (!tgt_off || (M > 0 && (!tgt_boxes || !tgt_labels || !best))) return DM_E_INVALID_ARG;
+    for (int s0 = 0; s0 < S; s0 += DM_MAX_SETS_PER_LAUNCH) {
+        const int n = std::min(DM_MAX_SETS_PER_LAUNCH, S - s0);
+        DmIndexSetArray arr;
+        int max_q = 0;
+        for (int i = 0; i < n; ++i) {
+            arr.s[i] = sets[s0 + i];
+            if (!arr.s[i].target_cls) return DM_E_INVALID_ARG;
+            max_q = std::max(max_q, arr.s[i].Q);
+        }
+        hipLaunchKernelGGL(rcnn_dense_kernel, dim3((max_q + 63) / 64, B, n), dim3(64), 0, st, arr, B, M, pos_threshold,
+                           neg_threshold, tgt_boxes, tgt_labels, tgt_off, best ? best + (size_t)s0 * M : nullptr, n_cls,
+                           num_pos ? num_pos + s0 : nullptr);
+        rc = dm::check_hip(hipGetLastError(), "rcnn_dense_kernel launch");
         if (rc != DM_OK) return rc;
     }
     return DM_OK;

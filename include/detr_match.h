@@ -193,6 +193,19 @@ int dm_frcnn_f32(const DmIndexSet *sets, int S, int B, int M, int W, float pos_t
                  uint64_t *pos_bits, int32_t *best, uint64_t *neg_bits, void *stream);
 
 /*
+ * dm_frcnn_dense_i64: the dense [B, Q] class targets that calc_cls_loss_with_ignore
+ * (/root/reference/models/co_detr/loss.py:143-161) scatters from the Faster-RCNN positives and negatives,
+ * written straight to sets[s].target_cls: n_cls for negatives, the label of the last positive target
+ * otherwise, -1 for predictions that are neither (ignored).  `best` is dm_frcnn_f32's output.
+ * num_pos (int32[S], may be NULL) receives the number of positive pairs of each set, the
+ * normaliser of loss.py:151 before its max(., 1).
+ */
+int dm_frcnn_dense_i64(const DmIndexSet *sets, int S, int B, int M, float pos_threshold,
+                       float neg_threshold, const float *tgt_boxes, const int64_t *tgt_labels,
+                       const int32_t *tgt_off, const int32_t *best, int64_t n_cls, int32_t *num_pos,
+                       void *stream);
+
+/*
  * Measurement aids (no counterpart in the reference).  With profiling enabled,
  * dm_match_f32 records HIP events on its stream before the cost kernels, between the cost
  * and the assignment kernels, and after the assignment kernels; dm_profile_read returns the

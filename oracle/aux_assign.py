@@ -104,3 +104,19 @@ def faster_rcnn_image(pred_boxes, gt_boxes, pos_threshold=0.7, neg_threshold=0.3
 def faster_rcnn(pred_boxes_bq4, target_boxes, pos_threshold=0.7, neg_threshold=0.3):
     res = [faster_rcnn_image(p, g, pos_threshold, neg_threshold) for p, g in zip(pred_boxes_bq4, target_boxes)]
     return [r[0] for r in res], [r[1] for r in res]
+
+
+def faster_rcnn_class_targets(pos, neg, labels, Q, n_cls):
+    """[B, Q] int64 class targets and the pair count, /root/reference/models/co_detr/loss.py:151-159:
+    -1 everywhere, then the labels of the positive pairs in list order (a later pair overwrites an
+    earlier one on the same prediction, as an in-order scatter does), then n_cls on the negatives."""
+    B = len(neg)
+    out = np.full((B, Q), -1, dtype=np.int64)
+    pairs = 0
+    for b in range(B):
+        src, tgt = pos[b]
+        for q, t in zip(src.tolist(), tgt.tolist()):
+            out[b, q] = labels[b][t]
+        pairs += len(src)
+        out[b, neg[b]] = n_cls
+    return out, pairs

@@ -34,6 +34,8 @@ atss, rcnn = ATSS(9), FasterRCNN()
 print(f"B={B} Q={Q} S={S} sum T={sum(len(t['boxes']) for t in targets)}")
 print(f"ATSS        GPU {timeit(lambda: atss.assign_many(dev_sets, dev_targets), 20):8.2f} ms/step")
 print(f"Faster-RCNN GPU {timeit(lambda: rcnn.assign_many(dev_sets, dev_targets), 20):8.2f} ms/step")
+print(f"Faster-RCNN GPU {timeit(lambda: rcnn.dense_class_targets(dev_sets, dev_targets, 91), 20):8.2f} ms/step "
+      "(dense class maps + pair counts, device-resident)")
 tb = [t["boxes"].numpy() for t in targets]
 t0 = time.perf_counter()
 aux_assign.atss(sets[0]["pred_boxes"].numpy(), tb, 9)

@@ -83,6 +83,63 @@ def test_all_sets_of_a_step_against_the_restatement():
         assert torch.equal(a0, b0) and torch.equal(a1, b1)
 
 
+def test_dense_class_targets_against_the_scatter_of_the_lists():
+    """The device-resident class map equals the reference's scatter (loss.py:153-159) of the index lists."""
+    from detr_amd.aux_assign import FasterRCNN
+    from oracle import aux_assign
+
+    sets, targets = _workload(11, B=9, Q=700, S=3)
+    sets.append({"pred_boxes": sets[0]["pred_boxes"][:, :130].clone()})        # a shorter set in the same launch
+    rng = np.random.default_rng(3)
+    for t in targets:
+        t["labels"] = torch.from_numpy(rng.integers(0, 91, len(t["boxes"])))
+    dev_sets = [{"pred_boxes": s["pred_boxes"].cuda()} for s in sets]
+    dev_targets = [{k: v.cuda() for k, v in t.items()} for t in targets]
+    tb = [t["boxes"].numpy() for t in targets]
+    labels = [t["labels"].numpy() for t in targets]
+    head = FasterRCNN(0.5, 0.3)
+    maps, num_pos = head.dense_class_targets(dev_sets, dev_targets, 91)
+    assert num_pos.dtype == torch.int32 and num_pos.is_cuda and len(maps) == 4
+    seen = set()
+    for s, out in enumerate(sets):
+        Q = out["pred_boxes"].shape[1]
+        pos, neg = aux_assign.faster_rcnn(out["pred_boxes"].numpy(), tb, 0.5, 0.3)
+        want, pairs = aux_assign.faster_rcnn_class_targets(pos, neg, labels, Q, 91)
+        assert maps[s].shape == (9, Q) and maps[s].dtype == torch.int64 and maps[s].is_cuda
+        np.testing.assert_array_equal(maps[s].cpu().numpy(), want)
+        assert int(num_pos[s]) == pairs
+        seen |= set(np.unique(want).tolist())
+    assert -1 in seen and 91 in seen and len(seen) > 5          # ignored, negative and positive entries all occur
+    # and the scatter of the product's own lists gives the same map
+    lists = head.assign_many(dev_sets, dev_targets)
+    for s, (pos, neg) in enumerate(lists):
+        want, pairs = aux_assign.faster_rcnn_class_targets([(a.numpy(), b.numpy()) for a, b in pos],
+                                                           [n.numpy() for n in neg], labels, maps[s].shape[1], 91)
+        np.testing.assert_array_equal(maps[s].cpu().numpy(), want)
+    # images without targets: everything negative, no pairs
+    none = [{"boxes": t["boxes"][:0], "labels": t["labels"][:0]} for t in dev_targets]
+    maps, num_pos = head.dense_class_targets(dev_sets[:2], none, 7)
+    assert all(bool((m == 7).all()) for m in maps) and num_pos.tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("name", aux_golden.AUX_CASES)
+def test_dense_class_targets_golden(name):
+    """Scatter of the golden lists (produced by the reference's module) against the device map."""
+    from detr_amd.aux_assign import FasterRCNN
+    from oracle import aux_assign
+
+    c = aux_golden.AuxCase(name)
+    outputs, targets = c.torch_inputs("cuda")
+    labels = [np.arange(len(t["boxes"]), dtype=np.int64) * 3 + 1 for t in targets]
+    targets = [dict(t, labels=torch.from_numpy(l).cuda()) for t, l in zip(targets, labels)]
+    maps, num_pos = FasterRCNN().dense_class_targets([outputs], targets, 1000)
+    # the golden pairs are target-major; their order within one target does not matter to the scatter
+    # (the predictions of one target are distinct)
+    want, pairs = aux_assign.faster_rcnn_class_targets(c.pos, c.neg, labels, c.Q, 1000)
+    np.testing.assert_array_equal(maps[0].cpu().numpy(), want)
+    assert int(num_pos[0]) == pairs
+
+
 def test_errors_and_edges():
     from detr_amd.aux_assign import ATSS, FasterRCNN
 
