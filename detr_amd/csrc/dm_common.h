@@ -89,6 +89,16 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned x)
     return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// Minimum over lanes 0..15 (the first DPP row), wave-uniform result.
+__device__ __forceinline__ unsigned row0_min_u32(unsigned x)
+{
+    x = dpp_min_step<DPP_QUAD_SWAP1, 0xF>(x);
+    x = dpp_min_step<DPP_QUAD_SWAP2, 0xF>(x);
+    x = dpp_min_step<DPP_ROW_SHR4, 0xF>(x);
+    x = dpp_min_step<DPP_ROW_SHR8, 0xF>(x);      // lanes 12..15 of each row: row minimum
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 15);
+}
+
 __device__ __forceinline__ int readlane_i32(int v, int lane)
 {
     return __builtin_amdgcn_readlane(v, lane);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                 const bool better = r < spc[k];
                 spc[k] = better ? r : spc[k];
                 pth[k] = better ? i : pth[k];
-                lmin = fmin(lmin, spc[k]);
+                lmin = (NCOL == 1) ? spc[k] : fmin(lmin, spc[k]);
             }
             DM_STAMP(1)
             // locate the minimum: high word, then (if several lanes share it) low word
@@ -433,6 +433,25 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(bool cand, unsig
     return at;
 }
 
+// narrow_to_minimum for candidates that all sit in lanes 0..15 (one DPP row: four reduction steps).
+__device__ __forceinline__ unsigned long long narrow_to_minimum_row0(bool cand, unsigned hi, unsigned lo, unsigned key)
+{
+    const unsigned mhi = dm::row0_min_u32(cand ? hi : 0xFFFFFFFFu);
+    bool mine = cand && hi == mhi;
+    unsigned long long at = __ballot(mine);
+    if (__popcll(at) > 1) {
+        const unsigned mlo = dm::row0_min_u32(mine ? lo : 0xFFFFFFFFu);
+        mine = mine && lo == mlo;
+        at = __ballot(mine);
+        if (__popcll(at) > 1) {
+            const unsigned K = dm::wave_max_u32(mine ? key : 0u);
+            mine = mine && key == K;
+            at = __ballot(mine);
+        }
+    }
+    return at;
+}
+
 // One workgroup of W wavefronts (W = blockDim.x / 64, 1..16) per problem with T < Q <= 64*W*NCOL
 // (up to 4096 columns with 16 wavefronts and 4 columns per thread).
 // Thread `tid` owns the columns (queries) j = tid + 64*W*k, k < NCOL, and keeps their reduced
@@ -475,9 +494,9 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
 #endif
 
     double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
-    uint4 *rec = reinterpret_cast<uint4 *>(u + t_cap);      // [2][16] published candidates: hi, lo, key, column
-    int *recr = reinterpret_cast<int *>(rec + 32);          // [2][16] row assigned to that column, or -1
-    int *col4row = recr + 32;                               // [t_cap]
+    // [2][16] published candidates: hi, lo, key, column | (row assigned to that column + 1) << 16
+    uint4 *rec = reinterpret_cast<uint4 *>(u + t_cap);
+    int *col4row = reinterpret_cast<int *>(rec + 32);       // [t_cap]
     int *row4col = col4row + t_cap;                         // [QCAP]
     int *pathL = row4col + QCAP;                            // [QCAP]
     int *remaining = pathL + QCAP;                          // [QCAP] list position -> column
@@ -582,7 +601,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 const bool better = r < spc[k];
                 spc[k] = better ? r : spc[k];
                 pth[k] = better ? i : pth[k];
-                lmin = fmin(lmin, spc[k]);
+                lmin = (NCOL == 1) ? spc[k] : fmin(lmin, spc[k]);
             }
             // the lane's candidate among its own columns (list-position rule on ties)
             unsigned key = 0;
@@ -598,29 +617,34 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             DM_STAMP(1)
             // the wave's candidate, published by its lane
             const unsigned long long at = narrow_to_minimum(true, hi, lo, key);
-            if (lane == __ffsll((long long)at) - 1) {
-                rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj);
-                recr[par * 16 + wave] = cr;
-            }
+            if (lane == __ffsll((long long)at) - 1)
+                rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj | ((unsigned)(cr + 1) << 16));
             DM_STAMP(2)
             __syncthreads();
             DM_STAMP(3)
             // every wave picks the workgroup's candidate from the W records
             const bool has = lane < W;
-            const uint4 x = rec[par * 16 + (has ? lane : 0)];
-            const int xr = recr[par * 16 + (has ? lane : 0)];
-            const unsigned long long win = narrow_to_minimum(has, x.x, x.y, x.z);
+            const uint4 x = rec[par * 16 + (lane & 15)];
+            const unsigned long long win = narrow_to_minimum_row0(has, x.x, x.y, x.z);
             const int wl = __ffsll((long long)win) - 1;
             const unsigned whi = (unsigned)dm::readlane_i32((int)x.x, wl);
             const unsigned wlo = (unsigned)dm::readlane_i32((int)x.y, wl);
             const unsigned K = (unsigned)dm::readlane_i32((int)x.z, wl);
-            const int jw = dm::readlane_i32((int)x.w, wl);
-            const int rw = dm::readlane_i32(xr, wl);
+            const unsigned jr = (unsigned)dm::readlane_i32((int)x.w, wl);
+            const int jw = (int)(jr & 0xFFFFu);
+            const int rw = (int)(jr >> 16) - 1;
             const double m = from_sortable_words(whi, wlo);
             if (!(m < INF)) {
                 if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
                 return;
             }
+            min_val = m;
+            par ^= 1;
+#ifdef DM_LAP_STAMPS
+            ++st_iters;
+#endif
+            // an unassigned column ends the row: it is neither removed from the list nor parked
+            if (rw == -1) { sink = jw; DM_STAMP(4) break; }
             const int pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
             // swap-with-last removal of column jw (every wave writes the same values)
             const int jl = __builtin_amdgcn_readfirstlane(jl_read);
@@ -636,13 +660,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                     scanned |= 1u << k;
                 }
             }
-            par ^= 1;
-            min_val = m;
             DM_STAMP(4)
-#ifdef DM_LAP_STAMPS
-            ++st_iters;
-#endif
-            if (rw == -1) { sink = jw; break; }
             i = rw;
         }
         if (sink < 0) {      // ran out of columns without reaching an unassigned one
@@ -652,34 +670,31 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
 
         // Row end: dual update of the scanned columns, augmentation along the predecessor
         // chain, un-parking, and the list back in its initial (reversed) order.
-        const int nsc = nc - n;
-        if (nsc == 1) {
-            // the first step already found an unassigned column: nothing changes but u[cur].
+        if (n == nc) {
+            // the first step already found an unassigned column: nothing changes but u[cur] and the
+            // assignment of that column; list and positions are untouched.
             // No barrier: every wave writes the shared words itself.
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                const int j = tid + BS * k;
-                if (j == sink) { r4c[k] = cur; v[k] = v_real[k]; }
-                posr[k] = nc - 1 - j;
+                if (tid + BS * k == sink) r4c[k] = cur;
                 spc[k] = INF;
             }
-            scanned = 0;
             if (lane == 0) {
                 u[cur] = min_val;                     // it was 0
                 col4row[cur] = sink;
                 row4col[sink] = cur;
-                remaining[nc - 1 - sink] = sink;      // undo the removal (slot nc-1 still holds column 0)
             }
         } else {
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
-                if ((scanned >> k) & 1u) {      // a column scanned in this row
-                    const int j = tid + BS * k;
+                const int j = tid + BS * k;
+                if ((scanned >> k) & 1u) {      // a column scanned in this row (all of them are assigned)
                     const double d = min_val - spc_real[k];
-                    if (j != sink) u[r4c[k]] += d;
+                    u[r4c[k]] += d;
                     v[k] = v_real[k] - d;
                     pathL[j] = pth[k];
                 }
+                if (j == sink) pathL[j] = pth[k];
             }
             if (tid == 0) u[cur] += min_val;
             __syncthreads();
@@ -695,15 +710,16 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 }
             }
             __syncthreads();
-            // refresh the assignments of the scanned columns (every owner for its own columns, in
-            // parallel); list and positions back to initial
+            // refresh the assignments of the scanned columns and of the sink (every owner for its own
+            // columns, in parallel); list and positions back to initial
 #pragma unroll
             for (int k = 0; k < NCOL; ++k) {
+                const int j = tid + BS * k;
                 if ((scanned >> k) & 1u) {
-                    const int j = tid + BS * k;
                     r4c[k] = row4col[j];
                     remaining[nc - 1 - j] = j;
                 }
+                if (j == sink) r4c[k] = row4col[j];
             }
             scanned = 0;
             for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
@@ -936,7 +952,7 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const int qcap = 64 * waves * NCOL;
-    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * (16 + 4) + (size_t)3 * qcap * 4;
+    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * 16 + (size_t)3 * qcap * 4;
     size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS and keep their cost rows in
     // it; many: more resident workgroups beat resident rows
