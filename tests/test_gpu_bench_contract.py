@@ -27,3 +27,23 @@ def test_bench_json_line():
         assert key in roof, key
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0 < rec["roofline_stress"]["frac"] < 1.0
+
+
+def test_bench_two_ranks_rehearsal():
+    """The multi-rank path of bench.py (launcher environment, fences, MAX over ranks, rank 0 prints) with two
+    ranks sharing the one GPU of the test box over gloo; the real runs use one GPU per rank over RCCL."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--share-gpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 64 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
+    assert "cpu_baseline" not in rec and "flat_path" not in rec      # rank 0 at N = 1 only
