@@ -4,21 +4,23 @@
 // /root/reference/models/matcher.py:93-95.  scipy's solver is the shortest-augmenting-
 // path algorithm of D. F. Crouse, "On implementing 2D rectangular assignment
 // algorithms", IEEE TAES 2016 (no initialisation phase, fp64 duals, the matrix is
-// transposed when it has more rows than columns).  Both kernels below run that
+// transposed when it has more rows than columns).  The kernels below run that
 // algorithm with the same fp64 operation order and reproduce scipy's choice among
 // tied minima, which depends on the position of a column in scipy's swap-with-last
 // "remaining" list:
 //     among the remaining columns of minimal reduced cost, take the unassigned one at
 //     the LARGEST list position if there is one, else the one at the SMALLEST position.
 //
-// One wavefront solves one (set, image) problem; there is no inter-workgroup traffic.
-//   lap_wave_kernel<NCOL>  T < Q <= 64*NCOL <= 1088: one wavefront per problem; every lane
-//                          owns NCOL columns (queries) and keeps their reduced cost, dual,
-//                          assignment and predecessor in registers; the column minimum is
-//                          located with 32-bit DPP wave reductions; the first rows of the
-//                          cost block are staged in LDS by LDS-DMA.
+// Every (set, image) problem is solved by one workgroup; there is no inter-workgroup traffic.
+//   lap_block_kernel<NCOL, WIDE>  T < Q <= 4096: a workgroup of 1..16 wavefronts per problem, a
+//                          thread owns NCOL columns (queries) in registers; per Dijkstra step a
+//                          DPP reduction per wavefront, one 128-bit record per wavefront in LDS,
+//                          one barrier, a second reduction.  Few problems in flight: latency.
+//   lap_wave_kernel<NCOL>  T < Q <= 64*NCOL <= 1088: one wavefront per problem, no barrier; every
+//                          lane owns NCOL columns.  Many problems in flight: throughput.
 //   lap_generic_kernel     any shape up to 4096 x 4096 (also T >= Q, where scipy does
 //                          not transpose): literal list-order scan with all state in LDS.
+// The first rows of a cost block are staged in LDS by LDS-DMA.
 #include <algorithm>
 #include <initializer_list>
 #include <type_traits>
@@ -269,11 +271,10 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                 cj = hit ? lane + 64 * k : cj;
                 cr = hit ? r4c[k] : cr;
             }
-            int jw, rw, pw;
+            int jw, rw, pw = -1;
             if (hits == 1) {
                 jw = dm::readlane_i32(cj, wl0);
                 rw = dm::readlane_i32(cr, wl0);
-                pw = __builtin_amdgcn_readfirstlane(pos[jw]);
             } else {
                 // several columns tie: the list-position rule decides
                 unsigned key = 0;
@@ -295,6 +296,12 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
             }
             DM_STAMP(3)
             min_val = m;
+#ifdef DM_LAP_STAMPS
+            ++st_iters;
+#endif
+            // an unassigned column ends the row: it is neither removed from the list nor parked
+            if (rw == -1) { sink = jw; DM_STAMP(4) break; }
+            if (pw < 0) pw = __builtin_amdgcn_readfirstlane(pos[jw]);
             // swap-with-last removal of column jw from the list
             if (lane == 0) {
                 remaining[pw] = jl;
@@ -311,10 +318,6 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                 }
             }, KSeq{});
             DM_STAMP(4)
-#ifdef DM_LAP_STAMPS
-            ++st_iters;
-#endif
-            if (rw == -1) { sink = jw; break; }
             i = rw;
         }
 
@@ -324,21 +327,18 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
         }
         // Row end: dual update of the scanned columns, augmentation along the predecessor
         // chain, un-parking, and the list back in its initial (reversed) order.
-        const int nsc = nc - n;
-        if (nsc == 1) {
-            // the first step already found an unassigned column: nothing changes but u[cur]
+        const int nsc = nc - n;      // scanned (parked) columns: all of them assigned
+        if (nsc == 0) {
+            // the first step already found an unassigned column: nothing changes but u[cur] and that
+            // column's assignment; the list is untouched
             with_static_index(sink >> 6, [&](auto kc) {
                 constexpr int K = decltype(kc)::value;
-                if (lane == (sink & 63)) { r4c[K] = cur; v[K] = v_real[K]; }
+                if (lane == (sink & 63)) r4c[K] = cur;
             }, KSeq{});
             if (lane == 0) {
                 u[cur] += min_val;
                 col4row[cur] = sink;
                 row4col[sink] = cur;
-                // undo the single removal: column 0 (initially last) had moved into sink's slot
-                const int p0 = nc - 1 - sink;
-                remaining[nc - 1] = 0; pos[0] = nc - 1;
-                remaining[p0] = sink; pos[sink] = p0;
             }
         } else {
             for (int e = 0; e < nsc; ++e) {
@@ -347,12 +347,16 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                     constexpr int K = decltype(kc)::value;
                     if (lane == (j & 63)) {
                         const double d = min_val - spc_real[K];
-                        if (j != sink) u[r4c[K]] += d;
+                        u[r4c[K]] += d;
                         v[K] = v_real[K] - d;
                         pathL[j] = pth[K];
                     }
                 }, KSeq{});
             }
+            with_static_index(sink >> 6, [&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (lane == (sink & 63)) pathL[sink] = pth[K];
+            }, KSeq{});
             if (lane == 0) u[cur] += min_val;
             __syncthreads();
             if (lane == 0) {
@@ -374,6 +378,10 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                     if (lane == (j & 63)) r4c[K] = row4col[j];
                 }, KSeq{});
             }
+            with_static_index(sink >> 6, [&](auto kc) {
+                constexpr int K = decltype(kc)::value;
+                if (lane == (sink & 63)) r4c[K] = row4col[sink];
+            }, KSeq{});
             // Every list slot that changed is either the initial slot of a scanned column or one
             // of the last nsc slots; both loops write initial values, overlaps agree.
             for (int e = lane; e < nsc; e += 64) {
