@@ -51,3 +51,20 @@ sz = sizes * 6
 f = torch.ops.aten.unsafe_split_with_sizes.default
 print("unsafe split x2", bench(lambda: (f(h[:6108], sz), f(h[6108:12216], sz))))
 print("split x2", bench(lambda: (h[:6108].split(sz), h[6108:12216].split(sz))))
+sz2 = sz * 2
+print("unsafe split, one call for both sides", bench(lambda: f(h[:12216], sz2)))
+print("Tensor.split, one call for both sides", bench(lambda: h[:12216].split(sz2)))
+def one_call_pairs():
+    parts = f(h[:12216], sz2)
+    n = len(sz)
+    pairs = list(zip(parts[:n], parts[n:]))
+    return [pairs[s * 64:(s + 1) * 64] for s in range(6)]
+def two_call_pairs():
+    pairs = list(zip(f(h[:6108], sz), f(h[6108:12216], sz)))
+    return [pairs[s * 64:(s + 1) * 64] for s in range(6)]
+print("one call + pairs", bench(one_call_pairs))
+print("two calls + pairs", bench(two_call_pairs))
+import gc
+gc.disable()
+print("gc off: one call + pairs", bench(one_call_pairs))
+print("gc off: two calls + pairs", bench(two_call_pairs))
