@@ -243,6 +243,27 @@ def test_workload_cfg4_full_size_properties():
     _check_workload("cfg4", lap_sample=24)
 
 
+def test_workload_cfg5_full_size_on_one_gpu():
+    """All 12 288 problems of cfg5 (B=1024, 12 sets) in one call: counts and index validity on every
+    problem, scipy equality on the GPU's own cost for a sample of images of every set."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg5", device="cuda")
+    result = detr_amd.HungarianMatcher(**wl.matcher_kwargs).match_many(sets, targets)
+    sizes = [len(t["labels"]) for t in targets]
+    assert len(result) == 12 and all(len(r) == 1024 for r in result)
+    for s in range(12):
+        for b, (src, tgt) in enumerate(result[s]):
+            src, tgt = src.numpy(), tgt.numpy()
+            assert len(src) == sizes[b] and np.all(np.diff(src) > 0)
+            assert sizes[b] == 0 or (src[0] >= 0 and src[-1] < 600)
+            assert sorted(tgt.tolist()) == list(range(sizes[b]))
+    del result, sets, targets
+    torch.cuda.empty_cache()
+    _check_workload("cfg5", lap_sample=6)
+
+
 @pytest.mark.parametrize("name", ["focal_c91_q100", "ce_c92_q100", "focal_c4_gamma15", "focal_c2_q300"])
 def test_cost_kernel_shape_knobs_do_not_change_the_cost(name):
     """Wavefronts per workgroup (C > 4 kernel), queries per thread and target split (C <= 4 kernel)
