@@ -579,7 +579,9 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
 
-        while (n > 0) {      // every step parks one column: at most nc steps
+        // Every step parks one column or ends the row; when no column is left every candidate is +inf,
+        // which ends the loop as infeasible: two exits only.
+        for (;;) {
 #ifdef DM_LAP_STAMPS
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
 #endif
@@ -642,10 +644,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             const int jw = (int)(jr & 0xFFFFu);
             const int rw = (int)(jr >> 16) - 1;
             const double m = from_sortable_words(whi, wlo);
-            if (!(m < INF)) {
-                if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
-                return;
-            }
+            if (!(m < INF)) break;      // sink stays -1
             min_val = m;
             par ^= 1;
 #ifdef DM_LAP_STAMPS
