@@ -427,15 +427,15 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(bool cand, unsig
 {
     const unsigned mhi = dm::wave_min_u32(cand ? hi : 0xFFFFFFFFu);
     bool mine = cand && hi == mhi;
-    unsigned long long at = __ballot(mine);
+    unsigned long long at = __builtin_amdgcn_ballot_w64(mine);
     if (__popcll(at) > 1) {
         const unsigned mlo = dm::wave_min_u32(mine ? lo : 0xFFFFFFFFu);
         mine = mine && lo == mlo;
-        at = __ballot(mine);
+        at = __builtin_amdgcn_ballot_w64(mine);
         if (__popcll(at) > 1) {
             const unsigned K = dm::wave_max_u32(mine ? key : 0u);
             mine = mine && key == K;
-            at = __ballot(mine);
+            at = __builtin_amdgcn_ballot_w64(mine);
         }
     }
     return at;
@@ -446,15 +446,15 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum_row0(bool cand, 
 {
     const unsigned mhi = dm::row0_min_u32(cand ? hi : 0xFFFFFFFFu);
     bool mine = cand && hi == mhi;
-    unsigned long long at = __ballot(mine);
+    unsigned long long at = __builtin_amdgcn_ballot_w64(mine);
     if (__popcll(at) > 1) {
         const unsigned mlo = dm::row0_min_u32(mine ? lo : 0xFFFFFFFFu);
         mine = mine && lo == mlo;
-        at = __ballot(mine);
+        at = __builtin_amdgcn_ballot_w64(mine);
         if (__popcll(at) > 1) {
             const unsigned K = dm::wave_max_u32(mine ? key : 0u);
             mine = mine && key == K;
-            at = __ballot(mine);
+            at = __builtin_amdgcn_ballot_w64(mine);
         }
     }
     return at;
@@ -616,18 +616,24 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             // the lane's candidate among its own columns (list-position rule on ties)
             unsigned key = 0;
             int cj = -1, cr = -1;
+            if (NCOL == 1) {
+                key = (r4c[0] == -1) ? (unsigned)(nc + 1 + posr[0]) : (unsigned)(nc - posr[0]);
+                cj = tid;
+                cr = r4c[0];
+            } else {
 #pragma unroll
-            for (int k = 0; k < NCOL; ++k) {
-                const bool hit = NCOL == 1 || spc[k] == lmin;
-                const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
-                if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
+                for (int k = 0; k < NCOL; ++k) {
+                    const bool hit = spc[k] == lmin;
+                    const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
+                    if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
+                }
             }
             unsigned hi, lo;
             sortable_words(lmin, hi, lo);
             DM_STAMP(1)
             // the wave's candidate, published by its lane
             const unsigned long long at = narrow_to_minimum(true, hi, lo, key);
-            if (lane == __ffsll((long long)at) - 1)
+            if (__builtin_amdgcn_inverse_ballot_w64(at & (0ull - at)))      // its lowest lane
                 rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj | ((unsigned)(cr + 1) << 16));
             DM_STAMP(2)
             __syncthreads();
@@ -643,8 +649,9 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             const unsigned jr = (unsigned)dm::readlane_i32((int)x.w, wl);
             const int jw = (int)(jr & 0xFFFFu);
             const int rw = (int)(jr >> 16) - 1;
+            // +inf maps to (0xFFF00000, 0), NaN above it: no finite candidate left
+            if (whi >= 0xFFF00000u) break;      // sink stays -1
             const double m = from_sortable_words(whi, wlo);
-            if (!(m < INF)) break;      // sink stays -1
             min_val = m;
             par ^= 1;
 #ifdef DM_LAP_STAMPS
