@@ -421,40 +421,31 @@ __device__ __forceinline__ double from_sortable_words(unsigned hi, unsigned lo)
     return __hiloint2double((int)(hi ^ (m | 0x80000000u)), (int)(lo ^ m));
 }
 
-// Lanes of `cand` whose (hi, lo[, key]) is the lexicographic minimum (key: maximum); returns
-// the lane mask after as few 32-bit wave reductions as the data needs.
-__device__ __forceinline__ unsigned long long narrow_to_minimum(bool cand, unsigned hi, unsigned lo, unsigned key)
+// More than one bit set in a wave-uniform lane mask (s_bcnt1 + compare; the generic popcount idiom
+// compiles to a four-instruction x & (x - 1) test).
+__device__ __forceinline__ bool several_lanes(unsigned long long mask)
 {
-    const unsigned mhi = dm::wave_min_u32(cand ? hi : 0xFFFFFFFFu);
-    bool mine = cand && hi == mhi;
-    unsigned long long at = __builtin_amdgcn_ballot_w64(mine);
-    if (__popcll(at) > 1) {
-        const unsigned mlo = dm::wave_min_u32(mine ? lo : 0xFFFFFFFFu);
-        mine = mine && lo == mlo;
-        at = __builtin_amdgcn_ballot_w64(mine);
-        if (__popcll(at) > 1) {
-            const unsigned K = dm::wave_max_u32(mine ? key : 0u);
-            mine = mine && key == K;
-            at = __builtin_amdgcn_ballot_w64(mine);
-        }
-    }
-    return at;
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(mask) : "scc");
+    return n > 1;
 }
 
-// narrow_to_minimum for candidates that all sit in lanes 0..15 (one DPP row: four reduction steps).
-__device__ __forceinline__ unsigned long long narrow_to_minimum_row0(bool cand, unsigned hi, unsigned lo, unsigned key)
+// Lanes of the wave-uniform mask `cand` whose (hi, lo[, key]) is the lexicographic minimum (key:
+// maximum); returns the lane mask after as few 32-bit reductions as the data needs.  All masks stay
+// in scalar registers.  ROW0: the candidates sit in lanes 0..15 (one DPP row: four reduction steps).
+template <bool ROW0>
+__device__ __forceinline__ unsigned long long narrow_to_minimum(unsigned long long cand, unsigned hi, unsigned lo,
+                                                                unsigned key)
 {
-    const unsigned mhi = dm::row0_min_u32(cand ? hi : 0xFFFFFFFFu);
-    bool mine = cand && hi == mhi;
-    unsigned long long at = __builtin_amdgcn_ballot_w64(mine);
-    if (__popcll(at) > 1) {
-        const unsigned mlo = dm::row0_min_u32(mine ? lo : 0xFFFFFFFFu);
-        mine = mine && lo == mlo;
-        at = __builtin_amdgcn_ballot_w64(mine);
-        if (__popcll(at) > 1) {
-            const unsigned K = dm::wave_max_u32(mine ? key : 0u);
-            mine = mine && key == K;
-            at = __builtin_amdgcn_ballot_w64(mine);
+    auto reduce_min = [](unsigned x) { return ROW0 ? dm::row0_min_u32(x) : dm::wave_min_u32(x); };
+    const unsigned mhi = reduce_min(__builtin_amdgcn_inverse_ballot_w64(cand) ? hi : 0xFFFFFFFFu);
+    unsigned long long at = __builtin_amdgcn_ballot_w64(hi == mhi) & cand;
+    if (several_lanes(at)) {
+        const unsigned mlo = reduce_min(__builtin_amdgcn_inverse_ballot_w64(at) ? lo : 0xFFFFFFFFu);
+        at &= __builtin_amdgcn_ballot_w64(lo == mlo);
+        if (several_lanes(at)) {
+            const unsigned K = dm::wave_max_u32(__builtin_amdgcn_inverse_ballot_w64(at) ? key : 0u);
+            at &= __builtin_amdgcn_ballot_w64(key == K);
         }
     }
     return at;
@@ -632,16 +623,15 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
             sortable_words(lmin, hi, lo);
             DM_STAMP(1)
             // the wave's candidate, published by its lane
-            const unsigned long long at = narrow_to_minimum(true, hi, lo, key);
+            const unsigned long long at = narrow_to_minimum<false>(~0ull, hi, lo, key);
             if (__builtin_amdgcn_inverse_ballot_w64(at & (0ull - at)))      // its lowest lane
                 rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj | ((unsigned)(cr + 1) << 16));
             DM_STAMP(2)
             __syncthreads();
             DM_STAMP(3)
             // every wave picks the workgroup's candidate from the W records
-            const bool has = lane < W;
             const uint4 x = rec[par * 16 + (lane & 15)];
-            const unsigned long long win = narrow_to_minimum_row0(has, x.x, x.y, x.z);
+            const unsigned long long win = narrow_to_minimum<true>((1ull << W) - 1ull, x.x, x.y, x.z);
             const int wl = __ffsll((long long)win) - 1;
             const unsigned whi = (unsigned)dm::readlane_i32((int)x.x, wl);
             const unsigned wlo = (unsigned)dm::readlane_i32((int)x.y, wl);
