@@ -98,6 +98,15 @@ __device__ __forceinline__ void sortable_words(double x, unsigned &hi, unsigned 
     lo = (unsigned)__double2loint(x) ^ m;
 }
 
+// More than one bit set in a wave-uniform lane mask (s_bcnt1 + compare; the generic popcount idiom
+// compiles to a four-instruction x & (x - 1) test).
+__device__ __forceinline__ bool several_lanes(unsigned long long mask)
+{
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(mask) : "scc");
+    return n > 1;
+}
+
 // One wavefront per problem with T < Q <= 64*NCOL.  Lane l owns the columns (queries)
 // j = l + 64*k, k < NCOL, and keeps their reduced cost, dual, assignment and predecessor in
 // registers.  A column that has been scanned (or lies past Q) is parked with reduced cost +inf
@@ -210,7 +219,9 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
 
-        while (n > 0) {      // every step parks one column: at most nc steps
+        // every step parks one column or ends the row; with no column left every candidate is +inf,
+        // which ends the loop as infeasible (sink stays -1): two exits only
+        for (;;) {
 #ifdef DM_LAP_STAMPS
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
 #endif
@@ -247,20 +258,15 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
             unsigned hi, lo;
             sortable_words(lmin, hi, lo);
             const unsigned mhi = dm::wave_min_u32(hi);
-            bool mine = hi == mhi;
-            unsigned long long at = __ballot(mine);
-            if (__popcll(at) > 1) {
-                const unsigned mlo = dm::wave_min_u32(mine ? lo : 0xFFFFFFFFu);
-                mine = mine && (lo == mlo);
-                at = __ballot(mine);
+            unsigned long long at = __builtin_amdgcn_ballot_w64(hi == mhi);
+            if (several_lanes(at)) {
+                const unsigned mlo = dm::wave_min_u32(__builtin_amdgcn_inverse_ballot_w64(at) ? lo : 0xFFFFFFFFu);
+                at &= __builtin_amdgcn_ballot_w64(lo == mlo);
             }
             const int wl0 = __ffsll((long long)at) - 1;
             const double m = __hiloint2double(dm::readlane_i32(__double2hiint(lmin), wl0),
                                               dm::readlane_i32(__double2loint(lmin), wl0));
-            if (!(m < INF)) {
-                if (lane == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
-                return;
-            }
+            if (!(m < INF)) break;
             DM_STAMP(2)
             // columns attaining it
             int hits = 0, cj = -1, cr = -1;
@@ -419,15 +425,6 @@ __device__ __forceinline__ double from_sortable_words(unsigned hi, unsigned lo)
 {
     const unsigned m = (hi & 0x80000000u) ? 0u : 0xFFFFFFFFu;    // top bit set <=> value was non-negative
     return __hiloint2double((int)(hi ^ (m | 0x80000000u)), (int)(lo ^ m));
-}
-
-// More than one bit set in a wave-uniform lane mask (s_bcnt1 + compare; the generic popcount idiom
-// compiles to a four-instruction x & (x - 1) test).
-__device__ __forceinline__ bool several_lanes(unsigned long long mask)
-{
-    int n;
-    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(mask) : "scc");
-    return n > 1;
 }
 
 // Lanes of the wave-uniform mask `cand` whose (hi, lo[, key]) is the lexicographic minimum (key:
