@@ -561,176 +561,184 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
 #ifdef DM_LAP_STAMPS
     st_c1 = __builtin_amdgcn_s_memtime();
 #endif
-    int par = 0;
-    unsigned scanned = 0;      // bit k: this thread's column k has been scanned (parked) in the current row
-    for (int cur = 0; cur < nr; ++cur) {
-        double min_val = 0.0;
-        int i = cur, n = nc, sink = -1;
+    // The solver proper, compiled twice: with every row of the block resident in LDS (the usual case)
+    // the per-step choice of where a row lives disappears from the step.
+    auto solve = [&](auto all_resident) __attribute__((always_inline)) -> bool {
+        constexpr bool ALLRES = decltype(all_resident)::value;
+        int par = 0;
+        unsigned scanned = 0;      // bit k: this thread's column k has been scanned (parked) in the current row
+        for (int cur = 0; cur < nr; ++cur) {
+            double min_val = 0.0;
+            int i = cur, n = nc, sink = -1;
 
-        // Every step parks one column or ends the row; when no column is left every candidate is +inf,
-        // which ends the loop as infeasible: two exits only.
-        for (;;) {
+            // Every step parks one column or ends the row; when no column is left every candidate is +inf,
+            // which ends the loop as infeasible: two exits only.
+            for (;;) {
 #ifdef DM_LAP_STAMPS
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
 #endif
-            const double ui = u[i];
-            const int jl_read = remaining[n - 1];     // column at the last list position
-            float c[NCOL];
-            if (i < R) {
-                const float *row = crow + i * ls;
+                const double ui = u[i];
+                const int jl_read = remaining[n - 1];     // column at the last list position
+                float c[NCOL];
+                if (ALLRES || i < R) {
+                    const float *row = crow + i * ls;
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
-            } else {
-                const float *row = cg + (size_t)i * qs;
+                    for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+                } else {
+                    const float *row = cg + (size_t)i * qs;
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
-                if (i == cur) {     // the only full read of a row that is not resident: validate it here
-                    bool badrow = false;
+                    for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+                    if (i == cur) {     // the only full read of a row that is not resident: validate it here
+                        bool badrow = false;
 #pragma unroll
-                    for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
-                    if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
+                        for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
+                        if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
+                    }
                 }
-            }
-            DM_STAMP(0)
-            double lmin = INF;
+                DM_STAMP(0)
+                double lmin = INF;
 #pragma unroll
-            for (int k = 0; k < NCOL; ++k) {
-                const double r = ((min_val + (double)c[k]) - ui) - v[k];   // +inf for parked columns
-                const bool better = r < spc[k];
-                spc[k] = better ? r : spc[k];
-                pth[k] = better ? i : pth[k];
-                lmin = (NCOL == 1) ? spc[k] : fmin(lmin, spc[k]);
+                for (int k = 0; k < NCOL; ++k) {
+                    const double r = ((min_val + (double)c[k]) - ui) - v[k];   // +inf for parked columns
+                    const bool better = r < spc[k];
+                    spc[k] = better ? r : spc[k];
+                    pth[k] = better ? i : pth[k];
+                    lmin = (NCOL == 1) ? spc[k] : fmin(lmin, spc[k]);
+                }
+                // the lane's candidate among its own columns (list-position rule on ties)
+                unsigned key = 0;
+                int cj = -1, cr = -1;
+                if (NCOL == 1) {
+                    key = (r4c[0] == -1) ? (unsigned)(nc + 1 + posr[0]) : (unsigned)(nc - posr[0]);
+                    cj = tid;
+                    cr = r4c[0];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NCOL; ++k) {
+                        const bool hit = spc[k] == lmin;
+                        const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
+                        if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
+                    }
+                }
+                unsigned hi, lo;
+                sortable_words(lmin, hi, lo);
+                DM_STAMP(1)
+                // the wave's candidate, published by its lane
+                const unsigned long long at = narrow_to_minimum<false>(~0ull, hi, lo, key);
+                if (__builtin_amdgcn_inverse_ballot_w64(at & (0ull - at)))      // its lowest lane
+                    rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj | ((unsigned)(cr + 1) << 16));
+                DM_STAMP(2)
+                __syncthreads();
+                DM_STAMP(3)
+                // every wave picks the workgroup's candidate from the W records
+                const uint4 x = rec[par * 16 + (lane & 15)];
+                const unsigned long long win = narrow_to_minimum<true>((1ull << W) - 1ull, x.x, x.y, x.z);
+                const int wl = __ffsll((long long)win) - 1;
+                const unsigned whi = (unsigned)dm::readlane_i32((int)x.x, wl);
+                const unsigned wlo = (unsigned)dm::readlane_i32((int)x.y, wl);
+                const unsigned K = (unsigned)dm::readlane_i32((int)x.z, wl);
+                const unsigned jr = (unsigned)dm::readlane_i32((int)x.w, wl);
+                const int jw = (int)(jr & 0xFFFFu);
+                const int rw = (int)(jr >> 16) - 1;
+                // +inf maps to (0xFFF00000, 0), NaN above it: no finite candidate left
+                if (whi >= 0xFFF00000u) break;      // sink stays -1
+                const double m = from_sortable_words(whi, wlo);
+                min_val = m;
+                par ^= 1;
+#ifdef DM_LAP_STAMPS
+                ++st_iters;
+#endif
+                // an unassigned column ends the row: it is neither removed from the list nor parked
+                if (rw == -1) { sink = jw; DM_STAMP(4) break; }
+                const int pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
+                // swap-with-last removal of column jw (every wave writes the same values)
+                const int jl = __builtin_amdgcn_readfirstlane(jl_read);
+                if (lane == 0) remaining[pw] = jl;
+                --n;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) {
+                    const int j = tid + BS * k;
+                    posr[k] = (j == jl) ? pw : posr[k];
+                    if (j == jw) {       // park the column in its owner's registers
+                        spc_real[k] = spc[k]; v_real[k] = v[k];
+                        spc[k] = INF; v[k] = NEG_INF;
+                        scanned |= 1u << k;
+                    }
+                }
+                DM_STAMP(4)
+                i = rw;
             }
-            // the lane's candidate among its own columns (list-position rule on ties)
-            unsigned key = 0;
-            int cj = -1, cr = -1;
-            if (NCOL == 1) {
-                key = (r4c[0] == -1) ? (unsigned)(nc + 1 + posr[0]) : (unsigned)(nc - posr[0]);
-                cj = tid;
-                cr = r4c[0];
+            if (sink < 0) {      // ran out of columns without reaching an unassigned one
+                if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
+                return false;
+            }
+
+            // Row end: dual update of the scanned columns, augmentation along the predecessor
+            // chain, un-parking, and the list back in its initial (reversed) order.
+            if (n == nc) {
+                // the first step already found an unassigned column: nothing changes but u[cur] and the
+                // assignment of that column; list and positions are untouched.
+                // No barrier: every wave writes the shared words itself.
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) {
+                    if (tid + BS * k == sink) r4c[k] = cur;
+                    spc[k] = INF;
+                }
+                if (lane == 0) {
+                    u[cur] = min_val;                     // it was 0
+                    col4row[cur] = sink;
+                    row4col[sink] = cur;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < NCOL; ++k) {
-                    const bool hit = spc[k] == lmin;
-                    const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
-                    if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
+                    const int j = tid + BS * k;
+                    if ((scanned >> k) & 1u) {      // a column scanned in this row (all of them are assigned)
+                        const double d = min_val - spc_real[k];
+                        u[r4c[k]] += d;
+                        v[k] = v_real[k] - d;
+                        pathL[j] = pth[k];
+                    }
+                    if (j == sink) pathL[j] = pth[k];
                 }
-            }
-            unsigned hi, lo;
-            sortable_words(lmin, hi, lo);
-            DM_STAMP(1)
-            // the wave's candidate, published by its lane
-            const unsigned long long at = narrow_to_minimum<false>(~0ull, hi, lo, key);
-            if (__builtin_amdgcn_inverse_ballot_w64(at & (0ull - at)))      // its lowest lane
-                rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj | ((unsigned)(cr + 1) << 16));
-            DM_STAMP(2)
-            __syncthreads();
-            DM_STAMP(3)
-            // every wave picks the workgroup's candidate from the W records
-            const uint4 x = rec[par * 16 + (lane & 15)];
-            const unsigned long long win = narrow_to_minimum<true>((1ull << W) - 1ull, x.x, x.y, x.z);
-            const int wl = __ffsll((long long)win) - 1;
-            const unsigned whi = (unsigned)dm::readlane_i32((int)x.x, wl);
-            const unsigned wlo = (unsigned)dm::readlane_i32((int)x.y, wl);
-            const unsigned K = (unsigned)dm::readlane_i32((int)x.z, wl);
-            const unsigned jr = (unsigned)dm::readlane_i32((int)x.w, wl);
-            const int jw = (int)(jr & 0xFFFFu);
-            const int rw = (int)(jr >> 16) - 1;
-            // +inf maps to (0xFFF00000, 0), NaN above it: no finite candidate left
-            if (whi >= 0xFFF00000u) break;      // sink stays -1
-            const double m = from_sortable_words(whi, wlo);
-            min_val = m;
-            par ^= 1;
-#ifdef DM_LAP_STAMPS
-            ++st_iters;
-#endif
-            // an unassigned column ends the row: it is neither removed from the list nor parked
-            if (rw == -1) { sink = jw; DM_STAMP(4) break; }
-            const int pw = (K > (unsigned)nc) ? (int)(K - (unsigned)nc - 1u) : (int)((unsigned)nc - K);
-            // swap-with-last removal of column jw (every wave writes the same values)
-            const int jl = __builtin_amdgcn_readfirstlane(jl_read);
-            if (lane == 0) remaining[pw] = jl;
-            --n;
+                if (tid == 0) u[cur] += min_val;
+                __syncthreads();
+                if (tid == 0) {
+                    int j = sink;
+                    for (int guard = 0; guard <= nr; ++guard) {
+                        const int ii = pathL[j];
+                        row4col[j] = ii;
+                        const int jn = col4row[ii];
+                        col4row[ii] = j;
+                        j = jn;
+                        if (ii == cur) break;
+                    }
+                }
+                __syncthreads();
+                // refresh the assignments of the scanned columns and of the sink (every owner for its own
+                // columns, in parallel); list and positions back to initial
 #pragma unroll
-            for (int k = 0; k < NCOL; ++k) {
-                const int j = tid + BS * k;
-                posr[k] = (j == jl) ? pw : posr[k];
-                if (j == jw) {       // park the column in its owner's registers
-                    spc_real[k] = spc[k]; v_real[k] = v[k];
-                    spc[k] = INF; v[k] = NEG_INF;
-                    scanned |= 1u << k;
+                for (int k = 0; k < NCOL; ++k) {
+                    const int j = tid + BS * k;
+                    if ((scanned >> k) & 1u) {
+                        r4c[k] = row4col[j];
+                        remaining[nc - 1 - j] = j;
+                    }
+                    if (j == sink) r4c[k] = row4col[j];
                 }
+                scanned = 0;
+                for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
+                // No barrier here: before the barrier of the next row's first step a wave reads only u[cur + 1]
+                // (untouched so far), cost rows and the last list slot, which it restores itself.
+                if (lane == 0) remaining[nc - 1] = 0;
             }
-            DM_STAMP(4)
-            i = rw;
-        }
-        if (sink < 0) {      // ran out of columns without reaching an unassigned one
-            if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
-            return;
         }
 
-        // Row end: dual update of the scanned columns, augmentation along the predecessor
-        // chain, un-parking, and the list back in its initial (reversed) order.
-        if (n == nc) {
-            // the first step already found an unassigned column: nothing changes but u[cur] and the
-            // assignment of that column; list and positions are untouched.
-            // No barrier: every wave writes the shared words itself.
-#pragma unroll
-            for (int k = 0; k < NCOL; ++k) {
-                if (tid + BS * k == sink) r4c[k] = cur;
-                spc[k] = INF;
-            }
-            if (lane == 0) {
-                u[cur] = min_val;                     // it was 0
-                col4row[cur] = sink;
-                row4col[sink] = cur;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NCOL; ++k) {
-                const int j = tid + BS * k;
-                if ((scanned >> k) & 1u) {      // a column scanned in this row (all of them are assigned)
-                    const double d = min_val - spc_real[k];
-                    u[r4c[k]] += d;
-                    v[k] = v_real[k] - d;
-                    pathL[j] = pth[k];
-                }
-                if (j == sink) pathL[j] = pth[k];
-            }
-            if (tid == 0) u[cur] += min_val;
-            __syncthreads();
-            if (tid == 0) {
-                int j = sink;
-                for (int guard = 0; guard <= nr; ++guard) {
-                    const int ii = pathL[j];
-                    row4col[j] = ii;
-                    const int jn = col4row[ii];
-                    col4row[ii] = j;
-                    j = jn;
-                    if (ii == cur) break;
-                }
-            }
-            __syncthreads();
-            // refresh the assignments of the scanned columns and of the sink (every owner for its own
-            // columns, in parallel); list and positions back to initial
-#pragma unroll
-            for (int k = 0; k < NCOL; ++k) {
-                const int j = tid + BS * k;
-                if ((scanned >> k) & 1u) {
-                    r4c[k] = row4col[j];
-                    remaining[nc - 1 - j] = j;
-                }
-                if (j == sink) r4c[k] = row4col[j];
-            }
-            scanned = 0;
-            for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
-#pragma unroll
-            for (int k = 0; k < NCOL; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
-            // No barrier here: before the barrier of the next row's first step a wave reads only u[cur + 1]
-            // (untouched so far), cost rows and the last list slot, which it restores itself.
-            if (lane == 0) remaining[nc - 1] = 0;
-        }
-    }
+        return true;
+    };
+    if (!(R >= nr ? solve(std::true_type{}) : solve(std::false_type{}))) return;
 
     __syncthreads();
 #ifdef DM_LAP_STAMPS
