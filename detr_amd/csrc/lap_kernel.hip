@@ -435,8 +435,9 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(unsigned long lo
                                                                 unsigned key)
 {
     auto reduce_min = [](unsigned x) { return ROW0 ? dm::row0_min_u32(x) : dm::wave_min_u32(x); };
-    const unsigned mhi = reduce_min(__builtin_amdgcn_inverse_ballot_w64(cand) ? hi : 0xFFFFFFFFu);
-    unsigned long long at = __builtin_amdgcn_ballot_w64(hi == mhi) & cand;
+    // ROW0 == false: every lane is a candidate
+    const unsigned mhi = reduce_min(ROW0 ? (__builtin_amdgcn_inverse_ballot_w64(cand) ? hi : 0xFFFFFFFFu) : hi);
+    unsigned long long at = ROW0 ? __builtin_amdgcn_ballot_w64(hi == mhi) & cand : __builtin_amdgcn_ballot_w64(hi == mhi);
     if (several_lanes(at)) {
         const unsigned mlo = reduce_min(__builtin_amdgcn_inverse_ballot_w64(at) ? lo : 0xFFFFFFFFu);
         at &= __builtin_amdgcn_ballot_w64(lo == mlo);
@@ -633,7 +634,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 // every wave picks the workgroup's candidate from the W records
                 const uint4 x = rec[par * 16 + (lane & 15)];
                 const unsigned long long win = narrow_to_minimum<true>((1ull << W) - 1ull, x.x, x.y, x.z);
-                const int wl = __ffsll((long long)win) - 1;
+                const int wl = __builtin_ctzll(win);      // never empty: some lane holds the minimum
                 const unsigned whi = (unsigned)dm::readlane_i32((int)x.x, wl);
                 const unsigned wlo = (unsigned)dm::readlane_i32((int)x.y, wl);
                 const unsigned K = (unsigned)dm::readlane_i32((int)x.z, wl);
