@@ -412,7 +412,8 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     }
 
     const int qs = set.q_stride;
-    float *out = cost + set.cost_off + (size_t)t0 * qs + q;
+    // wave-uniform row pointers (scalar registers); the lane's query is the 32-bit offset of the store
+    float *out = cost + set.cost_off + (size_t)t0 * qs;
 
     for (int tc = 0; tc < T; tc += TCHUNK) {
         const int nt = min(TCHUNK, T - tc);
@@ -436,27 +437,28 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
             };
             float *dst = out + (size_t)(tc + wave) * qs;
             const size_t hop = (size_t)W * qs;
+            const unsigned qu = (unsigned)q;      // unsigned 32-bit lane offset: scalar base + vector offset stores
             int i = wave;
             for (; i + W < nt; i += 2 * W, dst += 2 * hop) {
                 const float r0 = element(i), r1 = element(i + W);
 #if DM_TILE_ABL == 3
-                if (r0 == 123.456f) { dst[0] = r0; dst[hop] = r1; }
+                if (r0 == 123.456f) { dst[qu] = r0; dst[hop + qu] = r1; }
 #elif DM_TILE_NTST
-                __builtin_nontemporal_store(r0, dst);
-                __builtin_nontemporal_store(r1, dst + hop);
+                __builtin_nontemporal_store(r0, dst + qu);
+                __builtin_nontemporal_store(r1, dst + hop + qu);
 #else
-                dst[0] = r0;
-                dst[hop] = r1;
+                dst[qu] = r0;
+                dst[hop + qu] = r1;
 #endif
             }
             if (i < nt) {
                 const float r0 = element(i);
 #if DM_TILE_ABL == 3
-                if (r0 == 123.456f) dst[0] = r0;
+                if (r0 == 123.456f) dst[qu] = r0;
 #elif DM_TILE_NTST
-                __builtin_nontemporal_store(r0, dst);
+                __builtin_nontemporal_store(r0, dst + qu);
 #else
-                dst[0] = r0;
+                dst[qu] = r0;
 #endif
             }
         }
