@@ -66,17 +66,26 @@ extern "C" int dm_profile_read(float *cost_ms, float *lap_ms)
     return DM_OK;
 }
 
-extern "C" int dm_match_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
-                            const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
-                            const DmParams *params, float *cost, int64_t *src_out, int64_t *tgt_out,
-                            int32_t *status, void *stream)
+extern "C" int dm_match_flat_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
+                                 const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
+                                 const DmParams *params, float *cost, int64_t *src_out, int64_t *tgt_out,
+                                 int64_t *flat_out, int32_t *status, void *stream)
 {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g_profile) (void)hipEventRecord(g_ev[0], st);
     int rc = dm_cost_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, max_T, params, cost, status, stream);
     if (rc != DM_OK) return rc;
     if (g_profile) (void)hipEventRecord(g_ev[1], st);
-    rc = dm_lap_f32(sets, S, B, cost, tgt_off, order, max_T, src_out, tgt_out, status, stream);
+    rc = dm_lap_flat_f32(sets, S, B, cost, tgt_off, order, max_T, src_out, tgt_out, flat_out, status, stream);
     if (g_profile) { (void)hipEventRecord(g_ev[2], st); g_ev_valid = rc == DM_OK; }
     return rc;
+}
+
+extern "C" int dm_match_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
+                            const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
+                            const DmParams *params, float *cost, int64_t *src_out, int64_t *tgt_out,
+                            int32_t *status, void *stream)
+{
+    return dm_match_flat_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
+                             tgt_out, nullptr, status, stream);
 }

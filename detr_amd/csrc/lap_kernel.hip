@@ -69,14 +69,16 @@ __device__ __forceinline__ bool cost_is_invalid(float c)
 
 // Writes the matched (query, target) pairs in ascending query order: lanes hold, for
 // query j = lane + 64*k, the matched target (or -1) in r4c.
+// flat (optional): the target's position among the packed targets of the batch, target + flat_base.
 __device__ __forceinline__ void emit_pair(bool has, int query, int target, int &base, int lane,
-                                          int64_t *src, int64_t *tgt)
+                                          int64_t *src, int64_t *tgt, int64_t *flat = nullptr, int flat_base = 0)
 {
     const unsigned long long bal = __ballot(has);
     if (has) {
         const int o = base + __popcll(bal & ((1ull << lane) - 1ull));
         src[o] = query;
         tgt[o] = target;
+        if (flat) flat[o] = target + flat_base;
     }
     base += __popcll(bal);
 }
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                                                        const int32_t *__restrict__ tgt_off,
                                                        const int32_t *__restrict__ order,
                                                        int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
+        int64_t *__restrict__ flat_out,
                                                        int32_t *status, const int t_cap, const int lds_cost_floats)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -415,9 +418,10 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 #endif
     int64_t *so = src_out + set.out_off + t0;
     int64_t *to = tgt_out + set.out_off + t0;
+    int64_t *fo = flat_out ? flat_out + set.out_off + t0 : nullptr;
     int base = 0;
 #pragma unroll
-    for (int k = 0; k < NCOL; ++k) emit_pair(r4c[k] >= 0, lane + 64 * k, r4c[k], base, lane, so, to);
+    for (int k = 0; k < NCOL; ++k) emit_pair(r4c[k] >= 0, lane + 64 * k, r4c[k], base, lane, so, to, fo, t0);
 }
 
 // Inverse of sortable_words.
@@ -467,6 +471,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                                                          const int32_t *__restrict__ tgt_off,
                                                          const int32_t *__restrict__ order,
                                                          int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
+        int64_t *__restrict__ flat_out,
                                                          int32_t *status, const int t_cap, const int lds_cost_floats)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -753,11 +758,12 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     if (wave == 0) {
         int64_t *so = src_out + set.out_off + t0;
         int64_t *to = tgt_out + set.out_off + t0;
+        int64_t *fo = flat_out ? flat_out + set.out_off + t0 : nullptr;
         int base = 0;
         for (int j0 = 0; j0 < nc; j0 += 64) {
             const int j = j0 + lane;
             const int r = j < nc ? row4col[j] : -1;
-            emit_pair(r >= 0, j, r, base, lane, so, to);
+            emit_pair(r >= 0, j, r, base, lane, so, to, fo, t0);
         }
     }
 }
@@ -767,6 +773,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
                                                           const int32_t *__restrict__ tgt_off,
                                                           const int32_t *__restrict__ order,
                                                           int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
+        int64_t *__restrict__ flat_out,
                                                           int32_t *status, const int c_cap, const int r_cap,
                                                           const int all_problems, const int fast_max_q)
 {
@@ -871,15 +878,20 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
 
     int64_t *so = src_out + set.out_off + t0;
     int64_t *to = tgt_out + set.out_off + t0;
+    int64_t *fo = flat_out ? flat_out + set.out_off + t0 : nullptr;
     if (transposed) {
         int base = 0;
         for (int j0 = 0; j0 < nc; j0 += 64) {
             const int j = j0 + lane;
             const int r = j < nc ? row4col[j] : -1;
-            emit_pair(r >= 0, j, r, base, lane, so, to);
+            emit_pair(r >= 0, j, r, base, lane, so, to, fo, t0);
         }
     } else {
-        for (int i = lane; i < nr; i += 64) { so[i] = i; to[i] = col4row[i]; }
+        for (int i = lane; i < nr; i += 64) {
+            so[i] = i;
+            to[i] = col4row[i];
+            if (fo) fo[i] = col4row[i] + t0;
+        }
     }
 }
 
@@ -893,7 +905,7 @@ int ncol_class(int Q)
 
 template <int NCOL>
 int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out,
+                const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
                 int32_t *status, hipStream_t st)
 {
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
@@ -919,15 +931,15 @@ int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const in
         if (dev < 64) big_lds_devices |= 1ull << dev;
     }
     hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * B), dim3(64), fixed + want, st, arr, n, cost,
-                       tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
+                       tgt_off, order, src_out, tgt_out, flat_out, status, t_cap, (int)(want / sizeof(float)));
     return dm::check_hip(hipGetLastError(), "lap_wave_kernel launch");
 }
 
 int launch_wave_dyn(int ncol, const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                    const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out,
+                    const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
                     int32_t *status, hipStream_t st)
 {
-#define DM_CASE(N) case N: return launch_wave<N>(arr, n, B, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, status, st)
+#define DM_CASE(N) case N: return launch_wave<N>(arr, n, B, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, flat_out, status, st)
     switch (ncol) {
         DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
         DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
@@ -956,7 +968,7 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
 
 template <int NCOL>
 int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *cost, const int32_t *tgt_off,
-                 const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out,
+                 const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
                  int32_t *status, hipStream_t st)
 {
     const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
@@ -988,15 +1000,15 @@ int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *co
         if (dev < 64) big_lds_devices[wide] |= 1ull << dev;
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)n * B), dim3(64 * waves), fixed + want, st, arr, n,
-                       cost, tgt_off, order, src_out, tgt_out, status, t_cap, (int)(want / sizeof(float)));
+                       cost, tgt_off, order, src_out, tgt_out, flat_out, status, t_cap, (int)(want / sizeof(float)));
     return dm::check_hip(hipGetLastError(), "lap_block_kernel launch");
 }
 
 int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, const float *cost,
                      const int32_t *tgt_off, const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out,
-                     int64_t *tgt_out, int32_t *status, hipStream_t st)
+                     int64_t *tgt_out, int64_t *flat_out, int32_t *status, hipStream_t st)
 {
-#define DM_CASE(N) case N: return launch_block<N>(arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, status, st)
+#define DM_CASE(N) case N: return launch_block<N>(arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, flat_out, status, st)
     switch (ncol) {
         DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
         DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
@@ -1033,9 +1045,9 @@ int set_lap_knob(int knob, int value)
 }
 }  // namespace dm
 
-extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
-                          const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out,
-                          int32_t *status, void *stream)
+extern "C" int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
+                               const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
+                               int32_t *status, void *stream)
 {
     if (S < 0 || B < 0 || max_T < 0 || !status) return DM_E_INVALID_ARG;
     if (S == 0 || B == 0 || max_T == 0) return DM_OK;
@@ -1096,7 +1108,7 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
                 max_stride = std::max(max_stride, sets[s].q_stride);
             }
             int rc = launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out,
-                                      tgt_out, status, st);
+                                      tgt_out, flat_out, status, st);
             if (rc != DM_OK) return rc;
         }
     }
@@ -1128,9 +1140,9 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
                 if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
                     int rc = use_block
                                  ? launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, max_stride,
-                                                    src_out, tgt_out, status, st)
+                                                    src_out, tgt_out, flat_out, status, st)
                                  : launch_wave_dyn(ncol, arr, n, B, cost, tgt_off, order, max_T, Q, max_stride,
-                                                   src_out, tgt_out, status, st);
+                                                   src_out, tgt_out, flat_out, status, st);
                     if (rc != DM_OK) return rc;
                     n = 0;
                     max_stride = Q;
@@ -1161,11 +1173,18 @@ extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, co
                 if (rc != DM_OK) return rc;
             }
             hipLaunchKernelGGL(lap_generic_kernel, dim3((unsigned)n * B), dim3(64), lds, st, arr, n, cost, tgt_off,
-                               order, src_out, tgt_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0, fast_max_q);
+                               order, src_out, tgt_out, flat_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0, fast_max_q);
             int rc = dm::check_hip(hipGetLastError(), "lap_generic_kernel launch");
             if (rc != DM_OK) return rc;
             n = 0; max_Q = 0;
         }
     }
     return DM_OK;
+}
+
+extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
+                          const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out,
+                          int32_t *status, void *stream)
+{
+    return dm_lap_flat_f32(sets, S, B, cost, tgt_off, order, max_T, src_out, tgt_out, nullptr, status, stream);
 }

@@ -282,10 +282,10 @@ class HungarianMatcher(torch.nn.Module):
             dims.append(int(logits.shape[1]))
         return device, C, keep, dims
 
-    def _launch(self, outputs_list, packed: PackedTargets):
+    def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False):
         """Enqueue the cost and assignment kernels for all output sets on the current stream.
-        Returns the device buffer [src (S*M) | tgt (S*M) | status word], the queries per set, the
-        cost buffer and, per set, (offset, row stride) of its cost region."""
+        Returns the device buffer [src (S*M) | tgt (S*M) | status word (| flat (S*M))], the queries
+        per set, the cost buffer and, per set, (offset, row stride) of its cost region."""
         S, batch, M = len(outputs_list), packed.batch, packed.total
         device, C, keep, queries = self._prepare_sets(outputs_list, batch)
         if packed.device != device:
@@ -304,16 +304,18 @@ class HungarianMatcher(torch.nn.Module):
             cost_off += M * stride
 
         cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
-        out = torch.zeros(2 * S * M + 1, dtype=torch.int64, device=device)
+        # flat: a third index array behind the status word (position among the packed targets)
+        out = torch.zeros((3 if flat else 2) * S * M + 1, dtype=torch.int64, device=device)
         status_ptr = out.data_ptr() + 8 * 2 * S * M
         params = self._params()
         stream = torch.cuda.current_stream(device).cuda_stream
         with torch.cuda.device(device):
-            rc = lib.dm_match_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
-                                  packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(params),
-                                  cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M, status_ptr, stream)
-        _lib.check(rc, "dm_match_f32")
-        self.last_status = out[-1:]
+            rc = lib.dm_match_flat_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                                       packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(params),
+                                       cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M,
+                                       status_ptr + 8 if flat else None, status_ptr, stream)
+        _lib.check(rc, "dm_match_flat_f32")
+        self.last_status = out[2 * S * M:2 * S * M + 1]
         return out, queries, cost, strides
 
     @torch.no_grad()
@@ -395,11 +397,11 @@ class HungarianMatcher(torch.nn.Module):
         packed = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, device)
         if packed.batch == 0:
             return []
-        out, queries, _, _ = self._launch(outputs_list, packed)
+        out, queries, _, _ = self._launch(outputs_list, packed, flat=True)
         M, sizes = packed.total, packed.sizes
         both = out[:2 * S * M].view(2, S, M)
-        batch_idx, base = packed.batch_index, packed.target_base
-        flat_all = both[1] + base if M > 0 else both[1]       # one launch for every set
+        batch_idx = packed.batch_index
+        flat_all = out[2 * S * M + 1:].view(S, M)             # written by the assignment kernel itself
         result = []
         for s, q in enumerate(queries):
             src, tgt, flat = both[0, s], both[1, s], flat_all[s]

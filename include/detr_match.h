@@ -119,6 +119,22 @@ int dm_match_f32(const DmSet *sets, int S, int B, int C,
                  float *cost, int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
 
 /*
+ * dm_lap_f32 / dm_match_f32 with one more output for callers that keep the indices on the device:
+ * flat_out[k] = tgt_out[k] + tgt_off[image of k], the matched target's position among the packed
+ * targets of the batch -- what `torch.cat([t['boxes'][i] for t, (_, i) in zip(targets, indices)])`
+ * (detr/loss.py:103) gathers, as one index into the packed boxes.  Same layout as tgt_out; may be
+ * NULL (then identical to the calls above).
+ */
+int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cost,
+                    const int32_t *tgt_off, const int32_t *order, int max_T,
+                    int64_t *src_out, int64_t *tgt_out, int64_t *flat_out, int32_t *status, void *stream);
+int dm_match_flat_f32(const DmSet *sets, int S, int B, int C,
+                      const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
+                      const int32_t *order, int max_T, const DmParams *params,
+                      float *cost, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
+                      int32_t *status, void *stream);
+
+/*
  * ---- Consumers of the indices (the criterion's first steps after the matcher) ----------------
  * One output set as these entry points see it.  src / tgt are the buffers dm_lap_f32 wrote
  * (same layout, same out_off); everything stays on the device.
