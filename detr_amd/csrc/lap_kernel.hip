@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                                                        const int32_t *__restrict__ tgt_off,
                                                        const int32_t *__restrict__ order,
                                                        int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
-        int64_t *__restrict__ flat_out,
+                                                         int64_t *__restrict__ flat_out,
                                                        int32_t *status, const int t_cap, const int lds_cost_floats)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -463,7 +463,9 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(unsigned long lo
 // records the same way -- all waves agree on the step's column without a second barrier (the
 // records are double-buffered by step parity).  State that every wave needs (list, row
 // assignment of a one-step row) is written redundantly by each wave, so a wave only ever
-// depends on its own LDS writes between barriers.
+// depends on its own LDS writes between barriers.  The step loop has two exits only (row end,
+// nothing finite left) and its lane masks live in scalar registers: half of a step's instructions
+// used to be scalar control flow.  flat_out (optional): target index + tgt_off[image].
 // WIDE: compiled for up to 1024 threads whatever NCOL (the register budget of 16 wavefronts).
 template <int NCOL, bool WIDE>
 __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL)) void lap_block_kernel(const DmSetArray sets, const int S,
@@ -471,7 +473,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                                                          const int32_t *__restrict__ tgt_off,
                                                          const int32_t *__restrict__ order,
                                                          int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
-        int64_t *__restrict__ flat_out,
+                                                         int64_t *__restrict__ flat_out,
                                                          int32_t *status, const int t_cap, const int lds_cost_floats)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
                                                           const int32_t *__restrict__ tgt_off,
                                                           const int32_t *__restrict__ order,
                                                           int64_t *__restrict__ src_out, int64_t *__restrict__ tgt_out,
-        int64_t *__restrict__ flat_out,
+                                                         int64_t *__restrict__ flat_out,
                                                           int32_t *status, const int c_cap, const int r_cap,
                                                           const int all_problems, const int fast_max_q)
 {
