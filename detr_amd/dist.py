@@ -49,7 +49,7 @@ def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> tor
     device = torch.device(device)
     if device.type == "cuda":
         # pinned staging + asynchronous copy: the host does not wait for the stream
-        staged = torch.tensor(list(local_counts), dtype=torch.float32).pin_memory()
+        staged = torch.tensor(list(local_counts), dtype=torch.float32, pin_memory=True)
         counts = staged.to(device, non_blocking=True)
     else:
         counts = torch.tensor(list(local_counts), dtype=torch.float32, device=device)
