@@ -134,6 +134,21 @@ __device__ __forceinline__ float pair_cost(const PredBox &p, const TgtRec &g, fl
     return __builtin_fmaf(w_bbox, l1, __builtin_fmaf(w_giou, neg_giou, wcls));
 }
 
+// One target, validated and pre-converted, into its LDS record.
+__device__ __forceinline__ void store_target(TgtRec *slot, const float4 gb, long long l, int C, int32_t *status)
+{
+    TgtRec g;
+    g.cx = gb.x; g.cy = gb.y; g.w = gb.z; g.h = gb.w;
+    g.x0 = g.cx - 0.5f * g.w; g.y0 = g.cy - 0.5f * g.h;
+    g.x1 = g.cx + 0.5f * g.w; g.y1 = g.cy + 0.5f * g.h;
+    g.area = (g.x1 - g.x0) * (g.y1 - g.y0);
+    if (!((g.x1 >= g.x0) && (g.y1 >= g.y0))) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+    if (l < -(long long)C || l >= (long long)C) { dm::raise_status(status, DM_ST_LABEL_RANGE); l = 0; }
+    if (l < 0) l += C;   // python-style negative index
+    g.label = (int)l; g.pad0 = 0; g.pad1 = 0;
+    *slot = g;
+}
+
 // Stage targets [tc, tc + nt) of the image in LDS (validated, pre-converted).
 __device__ __forceinline__ void stage_targets(TgtRec *tg, const int64_t *__restrict__ labels,
                                               const float *__restrict__ tboxes, int first, int nt, int C,
@@ -141,18 +156,7 @@ __device__ __forceinline__ void stage_targets(TgtRec *tg, const int64_t *__restr
 {
     for (int i = threadIdx.x; i < nt; i += blockDim.x) {
         const int t = first + i;
-        const float4 gb = reinterpret_cast<const float4 *>(tboxes)[t];
-        long long l = labels[t];
-        TgtRec g;
-        g.cx = gb.x; g.cy = gb.y; g.w = gb.z; g.h = gb.w;
-        g.x0 = g.cx - 0.5f * g.w; g.y0 = g.cy - 0.5f * g.h;
-        g.x1 = g.cx + 0.5f * g.w; g.y1 = g.cy + 0.5f * g.h;
-        g.area = (g.x1 - g.x0) * (g.y1 - g.y0);
-        if (!((g.x1 >= g.x0) && (g.y1 >= g.y0))) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
-        if (l < -(long long)C || l >= (long long)C) { dm::raise_status(status, DM_ST_LABEL_RANGE); l = 0; }
-        if (l < 0) l += C;   // python-style negative index
-        g.label = (int)l; g.pad0 = 0; g.pad1 = 0;
-        tg[i] = g;
+        store_target(tg + i, reinterpret_cast<const float4 *>(tboxes)[t], labels[t], C, status);
     }
 }
 
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
 // rows (LDS-DMA when the tile starts on a 16-byte boundary: no registers, every piece in flight at
 // once).  Lane l reads row l: with an odd C the row stride is odd and the lanes hit distinct banks;
 // with an even C lane l walks its row rotated by l columns, which has the same effect.
-// One-dimensional grid, workgroup id = (set * B + image) * ntiles + tile.  (Giving all tiles of an
+// Grid (tile, image, set).  (Giving all tiles of an
 // image to workgroups of one XCD, so that the 256-byte pieces of a cost row meet in one L2, measured
 // 5 % slower: it concentrates the heavy images on single XCDs.)
 // MODE: 0 softmax class cost, 1 focal with gamma == 2, 2 focal with any gamma.
@@ -293,9 +297,10 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [16][64] softmax partials
     float *tile = part + (MODE == 0 ? 64 * 16 : 0);                                   // [64][C]
 
-    const int unit = blockIdx.x / ntiles, tile_id = blockIdx.x - unit * ntiles;
-    if (unit >= nsets * B) return;
-    const int si = unit / B, b = unit - si * B;
+    // grid (tiles, images, sets): no integer division in the prologue (each costs ~25 instructions, and
+    // this kernel is bound by the instructions it issues); x runs fastest, so the tiles of an image
+    // are still dispatched together
+    const int tile_id = blockIdx.x, b = blockIdx.y, si = blockIdx.z;
     const DmSet &set = sets.s[si];
     const int Q = set.Q;
     const int q0 = tile_id * 64;
@@ -309,6 +314,15 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     const size_t row = (size_t)b * Q + (active ? q : Q - 1);
 
     const float4 raw = reinterpret_cast<const float4 *>(set.boxes)[row];
+    // the first chunk of targets (one per thread) is requested before the tile, so that its latency
+    // runs under the tile's: loads complete in order, and the records are built while the tile streams
+    const bool stager = tid < min(TCHUNK, T);
+    float4 tgt_box = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    long long tgt_label = 0;
+    if (stager) {
+        tgt_box = reinterpret_cast<const float4 *>(tboxes)[t0 + tid];
+        tgt_label = labels[t0 + tid];
+    }
     if (T > 0) {
         // stream the tile: rows q0 .. q0+nq-1 are contiguous in memory and stay so in LDS
         const float *src = set.logits + ((size_t)b * Q + q0) * (size_t)C;
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
             }
             const int n4 = n & ~3;
             if (tid < n - n4) tile[n4 + tid] = src[n4 + tid];
+            if (stager) store_target(tg + tid, tgt_box, tgt_label, C, status);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if DM_TILE_ABL == 2
         } else if (false) {
@@ -344,8 +359,8 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
                     if (e < n) tile[e] = v[k];
                 }
             }
+            if (stager) store_target(tg + tid, tgt_box, tgt_label, C, status);
         }
-        stage_targets(tg, labels, tboxes, t0, min(TCHUNK, T), C, status);
     }
     const PredBox p = make_pred(raw);
     if (active && wave == 0 && !pred_valid(p)) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
@@ -561,11 +576,9 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
             if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
                 if (tile) {
                     const int ntiles = (Q + 63) / 64;
-                    const long long units = (long long)B * n;
-                    const long long wgs = units * ntiles;
-                    if (wgs > 0x7fffffffLL) return DM_E_UNSUPPORTED;
-                    hipLaunchKernelGGL(tile_fn, dim3((unsigned)wgs), dim3(64 * tile_waves), tile_lds, st, arr, n, B, C,
-                                       tgt_labels, tgt_boxes, tgt_off, *params, cost, status, ntiles);
+                    hipLaunchKernelGGL(tile_fn, dim3((unsigned)ntiles, (unsigned)B, (unsigned)n), dim3(64 * tile_waves),
+                                       tile_lds, st, arr, n, B, C, tgt_labels, tgt_boxes, tgt_off, *params, cost, status,
+                                       ntiles);
                 } else {
                     // one query per thread keeps the most wavefronts in flight; the two-query
                     // variant (8-byte stores) measured no faster at any size and stays a testing aid
