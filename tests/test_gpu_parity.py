@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the golden vectors, the CPU
 oracle and scipy.
 
-Bars (BASELINE.json north_star): cost entries within 1e-5 relative in fp32 (for the focal
+Bars: cost entries within 1e-5 relative in fp32 (for the focal
 class term widened by its sensitivity to a 2-ulp change of sigmoid(x), see
 golden_io.assert_cost_close); assignments
 bit-exact wherever the optimum is unique; total matched cost within 1e-5 relative where
