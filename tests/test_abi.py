@@ -61,6 +61,13 @@ def test_argument_validation_without_gpu():
     status = (ctypes.c_int32 * 1)(0)
     assert lib.dm_cost_f32(sets, 0, 0, 3, None, None, None, 0, ctypes.byref(prm), None, status, None) == 0
     assert lib.dm_lap_f32(sets, 1, 4, None, None, None, 0, None, None, status, None) == 0
+    # the variants with the packed-target index output share the checks
+    assert lib.dm_lap_flat_f32(sets, 1, 1, None, None, None, 4, None, None, None, None, None) == -1
+    assert lib.dm_lap_flat_f32(sets, 1, 4, None, None, None, 0, None, None, None, status, None) == 0
+    assert lib.dm_match_flat_f32(sets, -1, 1, 3, None, None, None, None, 0, ctypes.byref(prm), None, None, None, None,
+                                 status, None) == -1
+    assert lib.dm_match_flat_f32(sets, 0, 0, 3, None, None, None, None, 0, ctypes.byref(prm), None, None, None, None,
+                                 status, None) == 0
 
 
 def test_matcher_refuses_cpu_tensors():
@@ -91,6 +98,8 @@ def test_index_set_layout_and_consumer_argument_validation():
     assert lib.dm_target_classes_i64(sets, 0, 1, 0, None, None, None, None, 0, None) == 0          # nothing to do
     assert lib.dm_atss_f32(sets, 0, 1, 0, 65, None, None, None, None, None) == -3                  # k beyond 64
     assert lib.dm_frcnn_f32(sets, 0, 0, 0, 1, 0.7, 0.3, None, None, None, None, None, None) == 0
+    assert lib.dm_frcnn_dense_i64(sets, 1, 1, 0, 0.7, 0.3, None, None, None, None, 91, None, None) == -1   # Q = 0
+    assert lib.dm_frcnn_dense_i64(sets, 0, 1, 0, 0.7, 0.3, None, None, None, None, 91, None, None) == 0    # nothing to do
 
 
 def test_knobs_reject_values_they_do_not_know():
