@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("DETR_AMD_LIB") or os.path.join(_PKG, "libdetr_match.s
 
 ABI_VERSION = 1
 MAX_SETS_PER_LAUNCH = 16
+NOALLOC_MAX_COST_FLOATS = 8 << 20
 
 OK, E_INVALID_ARG, E_LAUNCH, E_UNSUPPORTED = 0, -1, -2, -3
 ST_LABEL_RANGE, ST_DEGENERATE_BOX, ST_INVALID_COST, ST_INFEASIBLE = 1, 2, 4, 8
@@ -40,7 +41,8 @@ class DmParams(ctypes.Structure):
 
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
-           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_profile_enable", "dm_profile_read",
+           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_noalloc_f32",
+           "dm_profile_enable", "dm_profile_read",
            "dm_debug_set_knob",
            "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
            "dm_atss_f32", "dm_frcnn_f32", "dm_frcnn_dense_i64"]
@@ -72,6 +74,8 @@ def _load():
     lib.dm_lap_flat_f32.argtypes = [setp, i32, i32, vp, vp, vp, i32, i64p, i64p, i64p, vp, vp]
     lib.dm_match_flat_f32.restype = ctypes.c_int
     lib.dm_match_flat_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, prmp, vp, i64p, i64p, i64p, vp, vp]
+    lib.dm_match_noalloc_f32.restype = ctypes.c_int
+    lib.dm_match_noalloc_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, i32, prmp, i64p, i64p, vp, vp]
     isetp = ctypes.POINTER(DmIndexSet)
     lib.dm_pair_loss_f32.restype = ctypes.c_int
     lib.dm_pair_loss_f32.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, vp, vp, vp]

@@ -1,4 +1,6 @@
 // Entry points of libdetr_match.so that are not a kernel launch of their own.
+#include <atomic>
+
 #include "dm_common.h"
 
 extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }
@@ -15,6 +17,7 @@ extern "C" const char *dm_strerror(int code)
 }
 
 namespace dm {
+int check_hip(hipError_t e, const char *what);
 int set_cost_knob(int knob, int value);
 int set_lap_knob(int knob, int value);
 }  // namespace dm
@@ -86,6 +89,59 @@ extern "C" int dm_match_f32(const DmSet *sets, int S, int B, int C, const int64_
                             const DmParams *params, float *cost, int64_t *src_out, int64_t *tgt_out,
                             int32_t *status, void *stream)
 {
+    return dm_match_flat_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
+                             tgt_out, nullptr, status, stream);
+}
+
+// ---- the entry point that allocates nothing ----------------------------------------------------
+// The cost blocks that travel from the cost kernel to the assignment kernel live in a fixed array of
+// device memory that belongs to the library (one copy per GPU, held until the process ends) instead
+// of a workspace the caller allocates.
+namespace {
+__device__ __align__(256) float scratch[DM_NOALLOC_MAX_COST_FLOATS];
+
+// In host code `scratch` is only a handle for hipGetSymbolAddress; the array's address differs from GPU to
+// GPU and is looked up once per device, with that device current.
+constexpr int MAX_DEVICES = 64;
+std::atomic<float *> g_scratch_ptr[MAX_DEVICES];
+
+int scratch_address(float **out)
+{
+    int dev = 0;
+    int rc = dm::check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc != DM_OK) return rc;
+    if (dev < 0 || dev >= MAX_DEVICES) return DM_E_UNSUPPORTED;
+    float *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void *addr = nullptr;
+        rc = dm::check_hip(hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+        if (rc != DM_OK) return rc;
+        if (!addr) return DM_E_LAUNCH;
+        p = static_cast<float *>(addr);
+        g_scratch_ptr[dev].store(p, std::memory_order_release);     // racing threads store the same address
+    }
+    *out = p;
+    return DM_OK;
+}
+}  // namespace
+
+extern "C" int dm_match_noalloc_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
+                                    const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
+                                    int M, const DmParams *params, int64_t *src_out, int64_t *tgt_out,
+                                    int32_t *status, void *stream)
+{
+    if (S < 0 || B < 0 || M < 0 || max_T < 0 || max_T > M) return DM_E_INVALID_ARG;
+    if (S > 0 && !sets) return DM_E_INVALID_ARG;
+    // every set's cost region [cost_off, cost_off + M * q_stride) must lie inside the fixed array
+    for (int s = 0; s < S; ++s) {
+        if (sets[s].cost_off < 0 || sets[s].q_stride < 1) return DM_E_INVALID_ARG;
+        const unsigned long long end = (unsigned long long)sets[s].cost_off +
+                                       (unsigned long long)M * (unsigned long long)sets[s].q_stride;
+        if (end > (unsigned long long)DM_NOALLOC_MAX_COST_FLOATS) return DM_E_UNSUPPORTED;
+    }
+    float *cost = nullptr;
+    const int rc = scratch_address(&cost);
+    if (rc != DM_OK) return rc;
     return dm_match_flat_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
                              tgt_out, nullptr, status, stream);
 }

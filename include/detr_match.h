@@ -135,6 +135,25 @@ int dm_match_flat_f32(const DmSet *sets, int S, int B, int C,
                       int32_t *status, void *stream);
 
 /*
+ * dm_match_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The cost
+ * blocks between the two kernels live in a fixed array of DM_NOALLOC_MAX_COST_FLOATS floats (32 MiB)
+ * that the library holds on every GPU it runs on until the process ends, so there is no `cost`
+ * argument; the call itself calls no hipMalloc / hipFree or other allocating routine.
+ *   M   host-known total number of targets, tgt_off[B]
+ * sets[s].cost_off / q_stride place set s inside that array as they do inside `cost` above: every set's
+ * region [cost_off, cost_off + M * q_stride) must end at or before DM_NOALLOC_MAX_COST_FLOATS, else
+ * DM_E_UNSUPPORTED (nothing is launched).  All calls on one GPU share the array: calls that overlap in time
+ * on the same GPU (two streams, two threads) race; serialise them.  Nothing in it needs clearing between
+ * calls (the assignment kernel reads only entries the cost kernel of the same call wrote).
+ */
+#define DM_NOALLOC_MAX_COST_FLOATS (8u << 20)
+int dm_match_noalloc_f32(const DmSet *sets, int S, int B, int C,
+                         const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
+                         const int32_t *order, int max_T, int M, const DmParams *params,
+                         int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
+
+/*
  * ---- Consumers of the indices (the criterion's first steps after the matcher) ----------------
  * One output set as these entry points see it.  src / tgt are the buffers dm_lap_f32 wrote
  * (same layout, same out_off); everything stays on the device.

@@ -70,6 +70,22 @@ def test_argument_validation_without_gpu():
                                  status, None) == 0
 
 
+def test_noalloc_entry_point_checks_its_limit_without_gpu():
+    """A request beyond the library's fixed cost array is refused before any HIP call."""
+    from detr_amd import _lib
+    from detr_amd._lib import DmParams, DmSet, lib
+
+    arr = (DmSet * 1)()
+    arr[0].cost_off, arr[0].out_off, arr[0].Q, arr[0].q_stride = 0, 0, 4096, 4096
+    prm = DmParams(1, 2.0, 5.0, 2.0, 0.25, 2.0)
+    M = _lib.NOALLOC_MAX_COST_FLOATS // 4096 + 1
+    assert lib.dm_match_noalloc_f32(arr, 1, 1, 2, None, None, None, None, 1, M, ctypes.byref(prm), None, None,
+                                    None, None) == _lib.E_UNSUPPORTED
+    arr[0].cost_off = -4
+    assert lib.dm_match_noalloc_f32(arr, 1, 1, 2, None, None, None, None, 1, 8, ctypes.byref(prm), None, None,
+                                    None, None) == _lib.E_INVALID_ARG
+
+
 def test_matcher_refuses_cpu_tensors():
     import pytest
     import torch
