@@ -8,9 +8,13 @@ one training step (cfg2: B=64 images, 6 decoder-layer sets, Q=600, ~16 targets p
 focal class cost) from "predictions and targets resident in HBM" to "CPU int64 index
 tensors in the caller's hands" -- i.e. packing the targets, the cost kernel, the
 assignment kernel, the device-to-host copy of the indices and the stream synchronisation.
-With N > 1 (one process per GPU, launched by torch.distributed.run) every rank matches
-its own B images (weak scaling) and the step also carries the single collective of the
-path, the all-reduce of the matched-box counts.
+With N > 1 there is one process per GPU: started by torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment), or -- when `python bench.py --gpus N` is run on its own -- by
+this script, which starts its N ranks as child processes before it touches a GPU.  Every rank
+matches its own B images (`--scaling weak`, the default) or its share of the workload's B images,
+dealt out by target count (`--scaling strong`), and the step also carries the single collective
+of the path, the all-reduce of the matched-box counts (asynchronous, waited for after the kernels
+have been enqueued).
 
 Prints one JSON line: whole-job matched images/s, plus
   roofline      cost kernel: algorithmic bytes per step / HIP-event time per step, vs 8 TB/s
@@ -22,6 +26,8 @@ import ctypes
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -190,13 +196,58 @@ def flat_path(matcher, sets, targets, device, steps):
             "what": "match_flat on pre-packed targets: device-resident flat indices, one sync after all steps"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this
+    one (which never touches a GPU), forward rank 0's output, fail if any rank fails."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                         stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    failed = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for rank in sorted(pending):
+            rc = children[rank].poll()
+            if rc is None:
+                continue
+            pending.discard(rank)
+            if rc != 0:
+                failed = (rank, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        # the other ranks would wait for the dead one in their next fence: end exactly the processes started here
+        for rank in pending:
+            children[rank].terminate()
+        for rank in pending:
+            try:
+                children[rank].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                children[rank].kill()
+    out = children[0].stdout.read() if children[0].stdout else ""
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if failed is not None:
+        raise SystemExit(f"rank {failed[0]} exited with status {failed[1]}")
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2")
-    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the workload's)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="images per GPU (weak) / in total (strong); default: the workload's")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank matches its own B images; strong: the B images of the workload are "
+                         "dealt to the ranks by target count (detr_amd.dist.balanced_shards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the cfg4-size cost-kernel measurement")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); gloo for rehearsals")
@@ -204,10 +255,13 @@ def main():
                     help="rehearsal only: all ranks use cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.share_gpu:
         local_rank = 0
@@ -222,18 +276,31 @@ def main():
 
     import detr_amd
     from detr_amd import synth
-    from detr_amd.dist import all_reduce_num_boxes, matched_box_counts
+    from detr_amd.dist import balanced_shards, matched_box_counts, start_num_boxes_all_reduce
 
-    wl, sets, targets = synth.make_workload(args.workload, device=device, batch=args.batch, rank=rank)
+    if args.scaling == "strong":
+        # the workload's B images in total: every rank draws the same target counts, takes the images
+        # balanced_shards deals to it and makes predictions for those only
+        import numpy as np
+
+        wl0 = synth.WORKLOADS[args.workload]
+        total_images = wl0.batch if args.batch is None else args.batch
+        all_counts = synth.target_counts(wl0.t_law, total_images, np.random.default_rng(wl0.seed))
+        mine = balanced_shards(all_counts.tolist(), world)[rank]
+        wl, sets, targets = synth.make_workload(args.workload, device=device, rank=rank, counts=all_counts[mine])
+    else:
+        wl, sets, targets = synth.make_workload(args.workload, device=device, batch=args.batch, rank=rank)
+        total_images = world * len(targets)
     B = len(targets)
     sizes = [len(t["labels"]) for t in targets]
     matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
     counts = matched_box_counts(sizes, wl.set_queries)
 
     def step():
-        if world > 1:
-            num_boxes = all_reduce_num_boxes(counts, device)   # overlaps the kernels below
+        pending = start_num_boxes_all_reduce(counts, device) if world > 1 else None   # asynchronous
         indices = matcher.match_many(sets, targets)
+        if pending is not None:
+            pending.result()        # the stream waits for the collective here, after the kernels were enqueued
         return indices
 
     def fence():
@@ -293,22 +360,22 @@ def main():
         achieved = algo_bytes / (cost_ms_avg * 1e-3) / 1e9
         record = {
             "metric": "matched images/sec (Q=600, ~16 GT/img, 6 aux layers); cost-kernel HBM GB/s",
-            "value": world * B * args.steps / elapsed,
+            "value": total_images * args.steps / elapsed,
             "unit": "images/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{wl.name}: B={B} images per GPU, sets Q={wl.set_queries}, C={wl.n_logits}, "
+            "config": {"workload": f"{wl.name}: B={B} images per GPU ({total_images} in total), sets Q={wl.set_queries}, C={wl.n_logits}, "
                                    f"{wl.cls_loss} class cost, T~{wl.t_law} (sum T={sum(sizes)}, max T={max(sizes)}), "
                                    f"{len(wl.set_queries) * B} assignment problems per step per GPU",
                        "parallelism": f"dp{world}", "python_gc": "paused while timing (as timeit does)"},
-            "with_python_gc": {"value": world * B * args.steps / elapsed_gc, "unit": "images/s",
+            "with_python_gc": {"value": total_images * args.steps / elapsed_gc, "unit": "images/s",
                                "ms_per_step": 1e3 * elapsed_gc / args.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -333,4 +400,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

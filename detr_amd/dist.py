@@ -41,11 +41,32 @@ def balanced_shards(target_sizes: Sequence[int], world_size: int) -> List[List[i
     return [sorted(s) for s in shards]
 
 
-def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> torch.Tensor:
-    """[S] float32 tensor on ``device``: clamp(sum over ranks / world_size, min=1).
+class PendingNumBoxes:
+    """The matched-box counts of a step on their way through the all-reduce.
 
-    One collective for all S output sets.  It can be issued right after the targets are
-    packed; it does not depend on the assignment."""
+    ``result()`` makes the caller's current stream (or, on the CPU, the caller) wait for the
+    collective and returns the [S] float32 tensor clamp(sum over ranks / world_size, min=1)."""
+
+    def __init__(self, counts: torch.Tensor, work, world: int):
+        self._counts, self._work, self._world = counts, work, world
+        self._done = None
+
+    def result(self) -> torch.Tensor:
+        if self._done is None:
+            if self._work is not None:
+                self._work.wait()       # nccl: a stream dependency, the host does not block
+            if self._world > 1:
+                self._counts.div_(self._world)
+            self._done = self._counts.clamp_(min=1.0)
+        return self._done
+
+
+def start_num_boxes_all_reduce(local_counts: Sequence[int], device, group=None) -> PendingNumBoxes:
+    """Issue the step's one collective -- all-reduce(SUM) of the S matched-box counts -- without
+    waiting for it (``async_op=True``: with the nccl backend RCCL runs it on its own stream).
+
+    The counts follow from tensor shapes, so this can be called right after the targets are known,
+    before the matching kernels are enqueued; ``result()`` is called where the loss needs the value."""
     device = torch.device(device)
     if device.type == "cuda":
         # pinned staging + asynchronous copy: the host does not wait for the stream
@@ -53,9 +74,15 @@ def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> tor
         counts = staged.to(device, non_blocking=True)
     else:
         counts = torch.tensor(list(local_counts), dtype=torch.float32, device=device)
+    work, world = None, 1
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
         if world > 1:
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-            counts.div_(world)
-    return counts.clamp_(min=1.0)
+            work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return PendingNumBoxes(counts, work, world)
+
+
+def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> torch.Tensor:
+    """[S] float32 tensor on ``device``: clamp(sum over ranks / world_size, min=1).
+    `start_num_boxes_all_reduce(...).result()` in one call."""
+    return start_num_boxes_all_reduce(local_counts, device, group).result()

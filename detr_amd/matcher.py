@@ -347,7 +347,7 @@ class HungarianMatcher(torch.nn.Module):
             host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
             host.copy_(out, non_blocking=True)
             done = self._done_event(device)
-            done.record()
+            done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
             # the per-image views depend on shapes only: build them while the GPU is working
             result = self._split(host, S, M, sizes, queries, packed.offsets_host)
             # by now the copy has normally landed: one event query is several times cheaper than a
@@ -429,7 +429,7 @@ class HungarianMatcher(torch.nn.Module):
         packed = targets if isinstance(targets, PackedTargets) else \
             PackedTargets(targets, outputs["pred_logits"].device)
         _, costs = self.match_many([outputs], packed, device_indices=True, return_cost=True)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(outputs["pred_logits"].device).synchronize()
         bits = int(self.last_status.item()) & 0xFFFFFFFF
         _raise_for_status(bits & (_lib.ST_LABEL_RANGE | _lib.ST_DEGENERATE_BOX))
         off = packed.offsets_host

@@ -85,15 +85,21 @@ def make_output_set(batch: int, queries: int, n_logits: int, gen: torch.Generato
     return {"pred_logits": logits.to(device), "pred_boxes": boxes.to(device)}
 
 
-def make_workload(name: str, device="cpu", batch: int = None, rank: int = 0):
+def make_workload(name: str, device="cpu", batch: int = None, rank: int = 0, counts=None):
     """Returns (workload, list of output-set dicts, targets) for one training step.
 
-    ``rank`` offsets the seed so data-parallel ranks hold different images.
+    ``rank`` offsets the seed so data-parallel ranks hold different images.  ``counts`` (targets
+    per image) overrides the workload's law and sets the batch size: a rank's share of a batch
+    whose images were dealt out by target count.
     """
     wl = WORKLOADS[name]
-    B = wl.batch if batch is None else batch
-    rng = np.random.default_rng(wl.seed + 7919 * rank)
-    counts = target_counts(wl.t_law, B, rng)
+    if counts is not None:
+        counts = np.asarray(counts, dtype=np.int64)
+        B = len(counts)
+    else:
+        B = wl.batch if batch is None else batch
+        rng = np.random.default_rng(wl.seed + 7919 * rank)
+        counts = target_counts(wl.t_law, B, rng)
     gen = torch.Generator(device="cpu").manual_seed(wl.seed + 7919 * rank)
     targets = make_targets(counts, wl.n_label_classes, gen, device)
     sets = []

@@ -29,9 +29,26 @@ def test_bench_json_line():
     assert 0 < rec["roofline_stress"]["frac"] < 1.0
 
 
-def test_bench_two_ranks_rehearsal():
-    """The multi-rank path of bench.py (launcher environment, fences, MAX over ranks, rank 0 prints) with two
-    ranks sharing the one GPU of the test box over gloo; the real runs use one GPU per rank over RCCL."""
+def _bench(*flags):
+    """`python bench.py ...` on its own, as the driver runs it: no launcher around it."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags, "--steps", "5", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=300, check=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_two_ranks():
+    """`bench.py --gpus 2` starts its two ranks itself (fences, MAX over ranks, rank 0 prints); here the
+    ranks share the one GPU of the test box over gloo, the real runs use one GPU per rank over RCCL."""
+    rec = _bench("--gpus", "2", "--backend", "gloo", "--share-gpu")
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 64 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
+    assert "cpu_baseline" not in rec and "flat_path" not in rec      # rank 0 at N = 1 only
+
+
+def test_bench_under_an_external_launcher():
+    """The same through torch.distributed.run, which sets RANK / LOCAL_RANK / WORLD_SIZE itself."""
     import socket
 
     with socket.socket() as s:
@@ -42,8 +59,24 @@ def test_bench_two_ranks_rehearsal():
            "--gpus", "2", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--share-gpu"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True).stdout
     lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                  # rank 0 only
+    assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp2"
-    assert rec["value"] > 0 and abs(rec["value"] - 2 * 64 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
-    assert "cpu_baseline" not in rec and "flat_path" not in rec      # rank 0 at N = 1 only
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2"
+
+
+def test_bench_strong_scaling_splits_the_batch():
+    """--scaling strong: the workload's 64 images in total, dealt to the two ranks by target count."""
+    rec = _bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--scaling", "strong")
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    assert "B=32 images per GPU (64 in total)" in rec["config"]["workload"]
+    assert abs(rec["value"] - 64 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
+
+
+def test_bench_two_ranks_over_rccl():
+    """One GPU per rank over RCCL (backend nccl): runs wherever the box has two GPUs."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    rec = _bench("--gpus", "2")
+    assert rec["n_gpus"] == 2 and rec["value"] > 0

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 import detr_amd
 from detr_amd import synth
-from detr_amd.dist import all_reduce_num_boxes, matched_box_counts, shard_range
+from detr_amd.dist import all_reduce_num_boxes, matched_box_counts, shard_range, start_num_boxes_all_reduce
 from detr_amd.matcher import HungarianMatcher, _raise_for_status
 
 
@@ -98,7 +98,9 @@ def _dp_worker(rank, world, port, results):
         lo, hi = shard_range(8, rank, world)
         sizes = [len(t["labels"]) for t in targets[lo:hi]]
         counts = matched_box_counts(sizes, [600] * 6 + [10])
-        out = all_reduce_num_boxes(counts, "cpu")
+        pending = start_num_boxes_all_reduce(counts, "cpu")      # asynchronous: the matcher would run here
+        out = pending.result()
+        assert pending.result() is out                            # waiting twice is harmless
         results[rank] = out.tolist()
     finally:
         dist.destroy_process_group()
@@ -133,3 +135,34 @@ def test_balanced_shards_even_out_images_and_targets():
         contiguous = [sum(sizes[r * 256 // world:(r + 1) * 256 // world]) for r in range(world)]
         assert max(loads) - min(loads) <= max(contiguous) - min(contiguous) or world == 1
     assert balanced_shards([], 4) == [[], [], [], []]
+
+
+def test_strong_scaling_shards_cover_the_workload():
+    """What `bench.py --scaling strong` gives every rank: its share of the workload's target counts."""
+    from detr_amd.dist import balanced_shards
+
+    wl = synth.WORKLOADS["cfg4"]
+    counts = synth.target_counts(wl.t_law, wl.batch, np.random.default_rng(wl.seed))
+    for world in (2, 4, 8):
+        shards = balanced_shards(counts.tolist(), world)
+        seen = []
+        for rank, mine in enumerate(shards):
+            _, sets, targets = synth.make_workload("cfg3", rank=rank, counts=counts[mine][:3])
+            assert [len(t["labels"]) for t in targets] == counts[mine][:3].tolist()
+            assert sets[0]["pred_logits"].shape[0] == 3
+            seen += mine
+        assert sorted(seen) == list(range(wl.batch))
+
+
+def test_bench_without_launcher_reports_a_failed_rank():
+    """`python bench.py --gpus 2` starts its own ranks; without a GPU they fail and the parent says so."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available():
+        pytest.skip("the ranks would run for real on a GPU box (covered by the gpu tests)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0 and "exited with status" in run.stderr
+    assert not [l for l in run.stdout.splitlines() if l.startswith("{")]
