@@ -29,7 +29,35 @@ def _stale():
     return any(os.path.getmtime(d) > built for d in deps)
 
 
+HELPER_SRC = os.path.join(CSRC, "index_views.cpp")
+HELPER = os.path.join(PKG, "_index_views.so")
+
+
+def build_helper(force=False, verbose=False):
+    """The host-side helper module detr_amd._index_views (bulk creation of the per-image index views;
+    plain C++ against the torch headers, no GPU code)."""
+    if not force and os.path.exists(HELPER) and os.path.getmtime(HELPER) >= os.path.getmtime(HELPER_SRC):
+        return HELPER
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension
+
+    libdir = cpp_extension.library_paths()[0]
+    cmd = ["g++", "-O2", "-shared", "-fPIC", "-std=c++17",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for inc in cpp_extension.include_paths() + [sysconfig.get_paths()["include"]]:
+        cmd += ["-I", inc]
+    cmd += [HELPER_SRC, "-o", HELPER, "-L", libdir, "-ltorch_python", "-ltorch", "-ltorch_cpu", "-lc10",
+            "-Wl,-rpath," + libdir]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return HELPER
+
+
 def build_library(force=False, verbose=False):
+    build_helper(force=force, verbose=verbose)
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -12,6 +12,7 @@ in one cost launch, one assignment launch and one device-to-host copy.
 
 There is no CPU path: inputs must live on a GPU and the HIP library must be built.
 """
+from itertools import accumulate
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import ctypes
@@ -25,6 +26,11 @@ from ._lib import DmParams, DmSet, lib
 Indices = List[Tuple[torch.Tensor, torch.Tensor]]
 
 _split_with_sizes = torch.ops.aten.unsafe_split_with_sizes.default
+
+try:        # bulk creation of the per-image index views (csrc/index_views.cpp, built by build_ext.py)
+    from . import _index_views
+except ImportError:      # not built: the views are made one by one in Python, same result
+    _index_views = None
 
 
 class PackedTargets:
@@ -41,8 +47,11 @@ class PackedTargets:
             sizes.append(b.shape[0])
             label_list.append(t["labels"])
             box_list.append(b)
+        # what `same_targets` compares a later call's targets with: the tensor objects themselves and
+        # their version counters (every in-place change of a tensor bumps its counter)
+        self._source = (label_list, box_list, [x._version for x in label_list], [x._version for x in box_list])
         self.sizes = sizes
-        self.batch = len(sizes)
+        self.batch = B = len(sizes)
         self.total = sum(sizes)
         self.max_t = max(sizes) if sizes else 0
         self.device = device
@@ -55,22 +64,41 @@ class PackedTargets:
                 raise RuntimeError(f"target boxes must be float32, got {boxes.dtype}")
             if labels.shape[0] != self.total:
                 raise ValueError("a target's labels and boxes differ in length")
-            self.labels = labels.to(torch.int64).contiguous()
-            self.boxes = boxes.reshape(-1, 4).contiguous()
+            self.labels = labels if labels.dtype == torch.int64 else labels.to(torch.int64)
+            self.boxes = boxes if boxes.dim() == 2 and boxes.shape[1] == 4 else boxes.reshape(-1, 4)
         else:
             if any(int(t.shape[0]) for t in label_list):
                 raise ValueError("a target's labels and boxes differ in length")
             self.labels = torch.zeros(1, dtype=torch.int64, device=device)
             self.boxes = torch.zeros(1, 4, dtype=torch.float32, device=device)
-        meta = np.empty(2 * self.batch + 1, dtype=np.int32)
-        meta[0] = 0
-        np.cumsum(self.sizes, out=meta[1:self.batch + 1])
-        # heavy images first: the assignment kernel's tail is set by the largest T
-        meta[self.batch + 1:] = np.argsort(-np.asarray(self.sizes, dtype=np.int64), kind="stable")
-        self.offsets_host = meta[:self.batch + 1]
-        staged = torch.empty(meta.shape[0], dtype=torch.int32, pin_memory=True)
-        staged.numpy()[:] = meta
+        # [offsets (B+1) | order (B)]: heavy images first, the assignment kernel's tail is set by the largest T
+        offsets = [0]
+        offsets.extend(accumulate(sizes))
+        self.offsets_list = offsets
+        order = sorted(range(B), key=sizes.__getitem__, reverse=True) if self.max_t > 0 else list(range(B))
+        staged = torch.tensor(offsets + order, dtype=torch.int32, pin_memory=True)
         self.meta = staged.to(device, non_blocking=True)
+
+    def same_targets(self, targets) -> bool:
+        """True when `targets` are the very tensors this object was packed from, unchanged since."""
+        src = getattr(self, "_source", None)
+        if src is None or len(targets) != self.batch:
+            return False
+        labels, boxes, label_versions, box_versions = src
+        i = 0
+        for t in targets:
+            l, b = t["labels"], t["boxes"]
+            if l is not labels[i] or b is not boxes[i] or l._version != label_versions[i] or b._version != box_versions[i]:
+                return False
+            i += 1
+        return True
+
+    @property
+    def offsets_host(self) -> np.ndarray:
+        """host int32 [B + 1]: exclusive prefix sums of the targets per image"""
+        if getattr(self, "_offsets_host", None) is None:
+            self._offsets_host = np.asarray(self.offsets_list, dtype=np.int32)
+        return self._offsets_host
 
     @classmethod
     def from_host(cls, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device) -> "PackedTargets":
@@ -108,7 +136,7 @@ class PackedTargets:
         meta[0] = 0
         np.cumsum(self.sizes, out=meta[1:B + 1])
         meta[B + 1:] = np.argsort(-np.asarray(self.sizes, dtype=np.int64), kind="stable")
-        self.offsets_host = meta[:B + 1].copy()
+        self.offsets_list = meta[:B + 1].tolist()
         dev = staged.to(device, non_blocking=True)
         self.boxes = dev[:off_labels].view(torch.float32).view(M, 4)
         self.labels = dev[off_labels:off_meta].view(torch.int64)
@@ -231,13 +259,25 @@ class HungarianMatcher(torch.nn.Module):
         self.focal_gamma = focal_gamma
         self.last_status = None
         self._events = {}
+        self._buffers = {}
+        self._packed = None
+        self._params_cache = None
 
     def __getstate__(self):
-        # per-device events and the last status view belong to this process and its streams
+        # per-device events and buffers, the packed targets and the last status view belong to this
+        # process and its streams
         state = self.__dict__.copy()
         state["_events"] = {}
+        state["_buffers"] = {}
+        state["_packed"] = None
+        state["_params_cache"] = None
         state["last_status"] = None
         return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None)):
+            self.__dict__.setdefault(name, value)
 
     def _done_event(self, device) -> torch.cuda.Event:
         key = device.index if device.index is not None else torch.cuda.current_device()
@@ -250,6 +290,15 @@ class HungarianMatcher(torch.nn.Module):
     def _params(self) -> DmParams:
         return DmParams(0 if self.cls_loss == "ce" else 1, float(self.cost_class), float(self.cost_bbox),
                         float(self.cost_giou), float(self.focal_alpha), float(self.focal_gamma))
+
+    def _params_ref(self):
+        """ctypes reference to the hyper-parameters, rebuilt only when an attribute has changed."""
+        key = (self.cls_loss, self.cost_class, self.cost_bbox, self.cost_giou, self.focal_alpha, self.focal_gamma)
+        cached = self._params_cache
+        if cached is None or cached[0] != key:
+            params = self._params()
+            cached = self._params_cache = (key, params, ctypes.byref(params))
+        return cached[2]
 
     @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets) -> Indices:
@@ -282,40 +331,88 @@ class HungarianMatcher(torch.nn.Module):
             dims.append(int(logits.shape[1]))
         return device, C, keep, dims
 
-    def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False):
+    def _packed_for(self, targets, device) -> PackedTargets:
+        """The packed form of `targets`; the previous call's when these are the same unchanged tensors
+        (the reference's criteria call the matcher once per decoder layer with the same targets,
+        /root/reference/models/detr/loss.py:164-169)."""
+        if isinstance(targets, PackedTargets):
+            return targets
+        cached = self._packed
+        if cached is not None and cached.device == device and cached.same_targets(targets):
+            return cached
+        self._packed = None          # (a failed packing must not leave a stale entry)
+        packed = PackedTargets(targets, device)
+        self._packed = packed
+        return packed
+
+    def _workspace(self, device, n_out: int, n_cost: int):
+        """Device buffers that live across calls, per device: the cost blocks (between the two kernels)
+        and, for the calls that hand CPU tensors back, the index buffer [status | src | tgt] -- its
+        status word sits in front so that it stays where it is when the buffer grows, and it is
+        cleared only after a call that set it."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        ws = self._buffers.get(key)
+        if ws is None:
+            ws = self._buffers[key] = {"out": None, "cost": None}
+        if n_out and (ws["out"] is None or ws["out"].shape[0] < n_out):
+            ws["out"] = torch.zeros(max(n_out, 4096), dtype=torch.int64, device=device)
+        if n_cost and (ws["cost"] is None or ws["cost"].shape[0] < n_cost):
+            ws["cost"] = torch.empty(n_cost, dtype=torch.float32, device=device)
+        return ws
+
+    def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False, own_buffers: bool = False):
         """Enqueue the cost and assignment kernels for all output sets on the current stream.
-        Returns the device buffer [src (S*M) | tgt (S*M) | status word (| flat (S*M))], the queries
-        per set, the cost buffer and, per set, (offset, row stride) of its cost region."""
+        Returns the device index buffer, the queries per set, the cost buffer and, per set, (offset, row
+        stride) of its cost region.  Index buffer: a fresh [src (S*M) | tgt (S*M) | status word (| flat
+        (S*M))] that the caller may keep, or with `own_buffers` this matcher's own [status | src | tgt],
+        valid until its next call."""
         S, batch, M = len(outputs_list), packed.batch, packed.total
         device, C, keep, queries = self._prepare_sets(outputs_list, batch)
         if packed.device != device:
             raise ValueError("targets and predictions must be on the same device")
-        if any(q == 0 for q in queries):
-            raise ValueError("an output set has no queries")
         sets = (DmSet * S)()
         cost_off = 0
         strides = []
-        for s, ((logits, boxes), q) in enumerate(zip(keep, queries)):
+        for s in range(S):
+            logits, boxes = keep[s]
+            q = queries[s]
+            if q == 0:
+                raise ValueError("an output set has no queries")
             stride = (q + 31) & ~31          # rows start on 128-byte lines
-            sets[s].logits, sets[s].boxes = logits.data_ptr(), boxes.data_ptr()
-            sets[s].cost_off, sets[s].out_off = cost_off, s * M
-            sets[s].Q, sets[s].q_stride = q, stride
+            d = sets[s]
+            d.logits, d.boxes = logits.data_ptr(), boxes.data_ptr()
+            d.cost_off, d.out_off = cost_off, s * M
+            d.Q, d.q_stride = q, stride
             strides.append((cost_off, stride))
             cost_off += M * stride
 
-        cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
-        # flat: a third index array behind the status word (position among the packed targets)
-        out = torch.zeros((3 if flat else 2) * S * M + 1, dtype=torch.int64, device=device)
-        status_ptr = out.data_ptr() + 8 * 2 * S * M
-        params = self._params()
+        SM = S * M
+        if own_buffers:
+            ws = self._workspace(device, 2 * SM + 1, max(cost_off, 1))
+            out, cost = ws["out"], ws["cost"]
+            status_ptr = out.data_ptr()
+            src_ptr = status_ptr + 8
+            flat_ptr = None
+            self.last_status = None
+        else:
+            cost = torch.empty(max(cost_off, 1), dtype=torch.float32, device=device)
+            # flat: a third index array behind the status word (position among the packed targets)
+            out = torch.zeros((3 if flat else 2) * SM + 1, dtype=torch.int64, device=device)
+            src_ptr = out.data_ptr()
+            status_ptr = src_ptr + 16 * SM
+            flat_ptr = status_ptr + 8 if flat else None
+            self.last_status = out[2 * SM:2 * SM + 1]
         stream = torch.cuda.current_stream(device).cuda_stream
-        with torch.cuda.device(device):
+        if device.index is None or device.index == torch.cuda.current_device():
             rc = lib.dm_match_flat_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
-                                       packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(params),
-                                       cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M,
-                                       status_ptr + 8 if flat else None, status_ptr, stream)
+                                       packed.offsets_ptr, packed.order_ptr, packed.max_t, self._params_ref(),
+                                       cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
+        else:
+            with torch.cuda.device(device):
+                rc = lib.dm_match_flat_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                                           packed.offsets_ptr, packed.order_ptr, packed.max_t, self._params_ref(),
+                                           cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
         _lib.check(rc, "dm_match_flat_f32")
-        self.last_status = out[2 * S * M:2 * S * M + 1]
         return out, queries, cost, strides
 
     @torch.no_grad()
@@ -329,32 +426,42 @@ class HungarianMatcher(torch.nn.Module):
         ``device_indices=True`` (no host synchronisation; input errors are then only
         raised by ``check_status()``).  With ``return_cost=True`` also returns, per set,
         the ``[M, Q]`` device cost tensor (rows = packed targets).
+
+        One matcher object serves one host thread at a time (it keeps device buffers between calls).
         """
         S = len(outputs_list)
         if S == 0:
             return []
         device = outputs_list[0]["pred_logits"].device
-        batch = targets.batch if isinstance(targets, PackedTargets) else len(targets)
-        packed = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, device)
+        packed = self._packed_for(targets, device)
         M, sizes = packed.total, packed.sizes
-        if batch == 0:
+        if packed.batch == 0:
             return [[] for _ in range(S)]
-        out, queries, cost, strides = self._launch(outputs_list, packed)
 
         if device_indices:
-            result = self._split(out, S, M, sizes, queries, packed.offsets_host)
+            out, queries, cost, strides = self._launch(outputs_list, packed)
+            result = self._split(out, S, M, sizes, queries, packed.offsets_list)
         else:
-            host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
-            host.copy_(out, non_blocking=True)
+            out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=not return_cost)
+            n = 2 * S * M + 1
+            host = torch.empty(n, dtype=torch.int64, pin_memory=True)
+            host.copy_(out[:n], non_blocking=True)
             done = self._done_event(device)
             done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
             # the per-image views depend on shapes only: build them while the GPU is working
-            result = self._split(host, S, M, sizes, queries, packed.offsets_host)
+            if return_cost:
+                result, status_at = self._split(host, S, M, sizes, queries, packed.offsets_list), n - 1
+            else:
+                result, status_at = self._split(host[1:], S, M, sizes, queries, packed.offsets_list), 0
             # by now the copy has normally landed: one event query is several times cheaper than a
             # stream synchronisation, which is only the fallback
             if not done.query():
                 done.synchronize()
-            _raise_for_status(int(host[-1]) & 0xFFFFFFFF)
+            bits = int(host[status_at]) & 0xFFFFFFFF
+            if bits:
+                if not return_cost:
+                    out[:1].zero_()          # the kept buffer's status word, for the next call
+                _raise_for_status(bits)
         if return_cost:
             costs = [cost[o:o + M * st].view(M, st)[:, :q] for (o, st), q in zip(strides, queries)]
             return result, costs
@@ -366,6 +473,8 @@ class HungarianMatcher(torch.nn.Module):
         if M == 0:
             empty = flat[:0]
             return [[(empty, empty) for _ in sizes] for _ in range(S)]
+        if _index_views is not None and flat.device.type == "cpu" and flat.dtype == torch.int64:
+            return _index_views.index_pairs(flat, M, sizes, queries, offsets)
         src_all, tgt_all = flat[:S * M], flat[S * M:2 * S * M]
         B = len(sizes)
         if min(queries) >= max(sizes):
@@ -394,7 +503,7 @@ class HungarianMatcher(torch.nn.Module):
         if S == 0:
             return []
         device = outputs_list[0]["pred_logits"].device
-        packed = targets if isinstance(targets, PackedTargets) else PackedTargets(targets, device)
+        packed = self._packed_for(targets, device)
         if packed.batch == 0:
             return []
         out, queries, _, _ = self._launch(outputs_list, packed, flat=True)
@@ -410,7 +519,7 @@ class HungarianMatcher(torch.nn.Module):
                 continue
             # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
             keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
-                                   for o, t in zip(packed.offsets_host[:-1], sizes)] + [np.zeros(0, np.int64)])
+                                   for o, t in zip(packed.offsets_list[:-1], sizes)] + [np.zeros(0, np.int64)])
             keep_dev = torch.from_numpy(keep).to(device)
             result.append(FlatMatches(batch_idx[keep_dev], src[keep_dev], tgt[keep_dev], flat[keep_dev], packed, q,
                                       (out, S), s))

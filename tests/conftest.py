@@ -12,7 +12,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     # a fresh checkout has no built library yet (it is git-ignored): build it once, where hipcc exists
     lib = os.path.join(ROOT, "detr_amd", "libdetr_match.so")
-    if not os.path.exists(lib) and not os.environ.get("DETR_AMD_LIB"):
+    helper = os.path.join(ROOT, "detr_amd", "_index_views.so")
+    if (not os.path.exists(lib) or not os.path.exists(helper)) and not os.environ.get("DETR_AMD_LIB"):
         import shutil
 
         if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):

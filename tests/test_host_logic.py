@@ -166,3 +166,74 @@ def test_bench_without_launcher_reports_a_failed_rank():
                          capture_output=True, text=True, timeout=120)
     assert run.returncode != 0 and "exited with status" in run.stderr
     assert not [l for l in run.stdout.splitlines() if l.startswith("{")]
+
+
+def _python_split(flat, S, M, sizes, queries, offsets):
+    import detr_amd.matcher as mm
+
+    helper, mm._index_views = mm._index_views, None
+    try:
+        return HungarianMatcher._split(flat, S, M, sizes, queries, offsets)
+    finally:
+        mm._index_views = helper
+
+
+def test_index_view_helper_equals_python_split_and_never_touches_live_tensors():
+    """detr_amd._index_views builds the per-image (src, tgt) views in bulk and recycles the tensor
+    objects of its previous call -- only those nobody else references any more."""
+    import weakref
+
+    from detr_amd.matcher import _index_views
+
+    assert _index_views is not None, "build_ext.py builds detr_amd/_index_views.so"
+    rng = np.random.default_rng(5)
+    for queries in ([600] * 6, [300, 7, 1050], [4]):
+        sizes = rng.poisson(9, 17).tolist() + [0]
+        S, M = len(queries), sum(sizes)
+        off = np.concatenate([[0], np.cumsum(sizes)]).tolist()
+        flat = torch.arange(2 * S * M + 1, dtype=torch.int64)
+        got = HungarianMatcher._split(flat, S, M, sizes, queries, off)
+        want = _python_split(flat, S, M, sizes, queries, off)
+        assert isinstance(got, list) and len(got) == S
+        for s in range(S):
+            assert isinstance(got[s], list) and len(got[s]) == len(sizes)
+            for pair, (w0, w1) in zip(got[s], want[s]):
+                assert isinstance(pair, tuple) and len(pair) == 2
+                assert pair[0].dtype == torch.int64 and torch.equal(pair[0], w0) and torch.equal(pair[1], w1)
+        # a view into a buffer with a storage offset (the matcher's [status | src | tgt] buffer)
+        shifted = torch.arange(2 * S * M + 2, dtype=torch.int64)[1:]
+        got = HungarianMatcher._split(shifted, S, M, sizes, queries, off)
+        want = _python_split(shifted, S, M, sizes, queries, off)
+        assert all(torch.equal(a0, b0) and torch.equal(a1, b1)
+                   for s in range(S) for (a0, a1), (b0, b1) in zip(got[s], want[s]))
+
+    sizes, queries = [3, 2], [5, 5]
+    S, M, off = 2, 5, [0, 3, 5]
+    first = torch.arange(21, dtype=torch.int64)
+    second = torch.arange(100, 121, dtype=torch.int64)
+    r1 = HungarianMatcher._split(first, S, M, sizes, queries, off)
+    held = r1[0][0][0]
+    r2 = HungarianMatcher._split(second, S, M, sizes, queries, off)     # r1 is alive: nothing of it may change
+    assert held.tolist() == [0, 1, 2] and r1[1][1][1].tolist() == [18, 19]
+    assert r2[0][0][0].tolist() == [100, 101, 102] and r2[0][0][0] is not held
+    del r1
+    r3 = HungarianMatcher._split(second, S, M, sizes, queries, off)     # `held` is still referenced
+    assert held.tolist() == [0, 1, 2] and r3[0][0][0] is not held
+    ids = {id(t) for r in r3 for pair in r for t in pair}
+    ref = weakref.ref(r3[1][0][0])
+    del r3
+    # two generations of objects are used in turn: the second call from here meets r3's objects again
+    r4 = HungarianMatcher._split(first, S, M, sizes, queries, off)
+    r5 = HungarianMatcher._split(first, S, M, sizes, queries, off)      # now they are recycled ...
+    recycled = {id(t) for r in r5 for pair in r for t in pair}
+    assert len(ids & recycled) >= 6
+    assert ref() is None                                                  # ... except the weakly referenced one
+    assert r5[1][1][1].tolist() == [18, 19] and r4[1][1][1].tolist() == [18, 19] and r2[1][1][1].tolist() == [118, 119]
+    # the usual loop keeps the previous result while the next is made: objects come back every other call
+    seen = []
+    result = None
+    for k in range(6):
+        result = HungarianMatcher._split(first if k % 2 else second, S, M, sizes, queries, off)
+        seen.append({id(t) for r in result for pair in r for t in pair})
+        assert result[0][0][0].tolist() == ([0, 1, 2] if k % 2 else [100, 101, 102])
+    assert len(seen[5] & seen[3]) >= 6

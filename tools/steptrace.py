@@ -18,20 +18,22 @@ dev = torch.device("cuda", 0)
 N = 300
 EV = torch.cuda.Event() if os.environ.get("USE_EVENT") else None
 acc = np.zeros(6)
+S = len(sets)
 for it in range(N + 20):
     t0 = time.perf_counter()
     packed = PackedTargets(targets, dev)
     t1 = time.perf_counter()
-    out, queries, cost, strides = m._launch(sets, packed)
+    out, queries, cost, strides = m._launch(sets, packed, own_buffers=True)
     t2 = time.perf_counter()
-    host = torch.empty(out.shape[0], dtype=torch.int64, pin_memory=True)
-    host.copy_(out, non_blocking=True)
+    n = 2 * S * packed.total + 1
+    host = torch.empty(n, dtype=torch.int64, pin_memory=True)
+    host.copy_(out[:n], non_blocking=True)
     if EV is not None:
         EV.record()
     if os.environ.get("SYNC_BEFORE_SPLIT"):
         torch.cuda.current_stream(dev).synchronize()
     t3 = time.perf_counter()
-    res = m._split(host, len(sets), packed.total, packed.sizes, queries, packed.offsets_host)
+    res = m._split(host[1:], S, packed.total, packed.sizes, queries, packed.offsets_list)
     t4 = time.perf_counter()
     if EV is not None:
         while not EV.query():
@@ -39,7 +41,7 @@ for it in range(N + 20):
     else:
         torch.cuda.current_stream(dev).synchronize()
     t5 = time.perf_counter()
-    _raise_for_status(int(host[-1]) & 0xFFFFFFFF)
+    _raise_for_status(int(host[0]) & 0xFFFFFFFF)
     t6 = time.perf_counter()
     if it >= 20:
         acc += np.diff([t0, t1, t2, t3, t4, t5, t6])
@@ -47,3 +49,15 @@ names = ["pack", "launch", "d2h enqueue", "split", "sync wait", "status"]
 for n, v in zip(names, acc / N * 1e6):
     print(f"{n:12s} {v:8.1f} us")
 print(f"{'total':12s} {acc.sum() / N * 1e6:8.1f} us")
+# the same step through the public call, with new target dicts every step (as a training loop has)
+import gc
+gc.disable()
+for label, fresh in (("match_many, new targets list per step", True), ("match_many, same targets object", False)):
+    for _ in range(20):
+        m.match_many(sets, list(targets) if fresh else targets)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(N):
+        m.match_many(sets, [dict(d) for d in targets] if fresh else targets)
+    torch.cuda.synchronize()
+    print(f"{label}: {(time.perf_counter() - t) / N * 1e6:.1f} us")
