@@ -1,7 +1,7 @@
 // Entry points of libdetr_match.so that are not a kernel launch of their own.
 #include <atomic>
 
-#include "dm_common.h"
+#include "cost_math.h"
 
 extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }
 
@@ -17,10 +17,13 @@ extern "C" const char *dm_strerror(int code)
 }
 
 namespace dm {
-int check_hip(hipError_t e, const char *what);
 int set_cost_knob(int knob, int value);
 int set_lap_knob(int knob, int value);
 }  // namespace dm
+
+namespace {
+int g_no_fuse = 0;      // DM_KNOB_FUSE: 1 = dm_match_fused_f32 always takes the two-kernel path (testing aid)
+}
 
 extern "C" int dm_debug_set_knob(int knob, int value)
 {
@@ -32,6 +35,10 @@ extern "C" int dm_debug_set_knob(int knob, int value)
     case DM_KNOB_COST_QPT:
     case DM_KNOB_COST_TSPLIT:
     case DM_KNOB_TILE_WAVES: return dm::set_cost_knob(knob, value);
+    case DM_KNOB_FUSE:
+        if (value < 0 || value > 1) return DM_E_INVALID_ARG;
+        g_no_fuse = value;
+        return DM_OK;
     }
     return DM_E_INVALID_ARG;
 }
@@ -84,13 +91,58 @@ extern "C" int dm_match_flat_f32(const DmSet *sets, int S, int B, int C, const i
     return rc;
 }
 
+// One step with the cost blocks computed inside the assignment kernels wherever that is possible
+// (C <= 4 and the set's problems all have T < Q); the other sets go through the cost kernel first.
+extern "C" int dm_match_fused_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
+                                  const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
+                                  const DmParams *params, float *workspace, int64_t *src_out, int64_t *tgt_out,
+                                  int64_t *flat_out, int32_t *status, void *stream)
+{
+    if (S < 0 || B < 0 || C < 1 || max_T < 0 || !params || !status) return DM_E_INVALID_ARG;
+    if (g_no_fuse || !dm::lap_can_fuse(C, max_T) || S > 4096)
+        return dm_match_flat_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, workspace,
+                                 src_out, tgt_out, flat_out, status, stream);
+    if (S == 0 || B == 0) return DM_OK;
+    if (!sets || !tgt_off || !src_out || !tgt_out || (max_T > 0 && (!tgt_labels || !tgt_boxes || !workspace)))
+        return DM_E_INVALID_ARG;
+    for (int s = 0; s < S; ++s)
+        if (!sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned char generic[4096];      // sets whose cost blocks some kernel reads from memory
+    int rc = dm::lap_plan(sets, S, B, max_T, generic);
+    if (rc != DM_OK) return rc;
+    if (g_profile) (void)hipEventRecord(g_ev[0], st);
+    // the sets the list-order kernel will touch need their cost blocks in memory
+    DmSet subset[DM_MAX_SETS_PER_LAUNCH];
+    int n = 0;
+    for (int s = 0; s <= S; ++s) {
+        if (s < S && generic[s]) subset[n++] = sets[s];
+        if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
+            rc = dm_cost_f32(subset, n, B, C, tgt_labels, tgt_boxes, tgt_off, max_T, params, workspace, status, stream);
+            if (rc != DM_OK) return rc;
+            n = 0;
+        }
+    }
+    if (g_profile) (void)hipEventRecord(g_ev[1], st);
+    if (max_T == 0) {
+        // no targets anywhere: nothing to assign, but the reference still validates every prediction box
+        rc = dm_cost_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, max_T, params, workspace, status, stream);
+    } else {
+        const dm::FusedIn fin{tgt_labels, tgt_boxes, *params, C};
+        rc = dm::lap_run(sets, S, B, workspace, tgt_off, order, max_T, src_out, tgt_out, flat_out, status, st, &fin,
+                         workspace);
+    }
+    if (g_profile) { (void)hipEventRecord(g_ev[2], st); g_ev_valid = rc == DM_OK; }
+    return rc;
+}
+
 extern "C" int dm_match_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
                             const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,
                             const DmParams *params, float *cost, int64_t *src_out, int64_t *tgt_out,
                             int32_t *status, void *stream)
 {
-    return dm_match_flat_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
-                             tgt_out, nullptr, status, stream);
+    return dm_match_fused_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
+                              tgt_out, nullptr, status, stream);
 }
 
 // ---- the entry point that allocates nothing ----------------------------------------------------
@@ -142,6 +194,6 @@ extern "C" int dm_match_noalloc_f32(const DmSet *sets, int S, int B, int C, cons
     float *cost = nullptr;
     const int rc = scratch_address(&cost);
     if (rc != DM_OK) return rc;
-    return dm_match_flat_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
-                             tgt_out, nullptr, status, stream);
+    return dm_match_fused_f32(sets, S, B, C, tgt_labels, tgt_boxes, tgt_off, order, max_T, params, cost, src_out,
+                              tgt_out, nullptr, status, stream);
 }

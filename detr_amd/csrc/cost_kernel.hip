@@ -21,9 +21,11 @@
 // separately rounded operations, far inside the 1e-5 parity bar.
 #include <algorithm>
 
-#include "dm_common.h"
+#include "cost_math.h"
 
 namespace {
+
+using namespace dm;
 
 constexpr int TCHUNK = 64;   // targets staged per pass
 #ifndef DM_TILE_ABL
@@ -41,113 +43,6 @@ constexpr int TCHUNK = 64;   // targets staged per pass
 #ifndef DM_TILE_NTST
 #define DM_TILE_NTST 0
 #endif
-
-struct __align__(16) TgtRec {
-    float x0, y0, x1, y1;    // box_ops.py:17-21
-    float cx, cy, w, h;
-    float area;              // (x1 - x0) * (y1 - y0), torchvision box_area
-    int label;               // wrapped into [0, C)
-    int pad0, pad1;
-};
-static_assert(sizeof(TgtRec) == 48, "TgtRec is read as three 16-byte LDS loads");
-
-// v_min_f32 / v_max_f32 without the canonicalising copies the compiler adds for possibly
-// signalling NaN inputs: boxes with NaN coordinates are rejected through the status word.
-__device__ __forceinline__ float fast_min(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float fast_max(float a, float b)
-{
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-__device__ __forceinline__ float pow_gamma(float x, float gamma)
-{
-    // torch computes pow(x, 2.0) as x * x
-    if (gamma == 2.0f) return x * x;
-    if (gamma == 1.0f) return x;
-    if (gamma == 0.0f) return 1.0f;
-    return powf(x, gamma);
-}
-
-// matcher.py:76-81 for one logit.
-// sigmoid and its complement are formed from a = exp(-|x|) as 1/(1+a) and a/(1+a): the
-// complement keeps full relative accuracy where the reference's fp32 `1 - p` has lost it
-// (it stays within one rounding of p of the reference's value); exp and log are the
-// hardware v_exp_f32 / v_log_f32 (1 ulp).
-// G2: gamma == 2 is known at compile time (keeps the general powf out of the instruction stream).
-template <bool G2 = false>
-__device__ __forceinline__ float focal_cost(float x, float alpha, float gamma)
-{
-    const float a = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896f);
-    const float big = __builtin_amdgcn_rcpf(1.0f + a);     // sigmoid(|x|)
-    const float small = a * big;                            // sigmoid(-|x|)
-    const float p = x >= 0.0f ? big : small;
-    const float q = x >= 0.0f ? small : big;                // 1 - p
-    const float nlog_q = -(__builtin_amdgcn_logf(q + 1e-8f) * 0.693147180559945f);
-    const float nlog_p = -(__builtin_amdgcn_logf(p + 1e-8f) * 0.693147180559945f);
-    const float neg = ((1.0f - alpha) * (G2 ? p * p : pow_gamma(p, gamma))) * nlog_q;
-    const float pos = (alpha * (G2 ? q * q : pow_gamma(q, gamma))) * nlog_p;
-    return pos - neg;
-}
-
-struct PredBox {
-    float cx, cy, w, h, x0, y0, x1, y1, area;
-};
-
-__device__ __forceinline__ PredBox make_pred(const float4 raw)
-{
-    PredBox p;
-    p.cx = raw.x; p.cy = raw.y; p.w = raw.z; p.h = raw.w;
-    p.x0 = p.cx - 0.5f * p.w; p.y0 = p.cy - 0.5f * p.h;
-    p.x1 = p.cx + 0.5f * p.w; p.y1 = p.cy + 0.5f * p.h;
-    p.area = (p.x1 - p.x0) * (p.y1 - p.y0);
-    return p;
-}
-
-__device__ __forceinline__ bool pred_valid(const PredBox &p)
-{
-    return (p.x1 >= p.x0) && (p.y1 >= p.y0);   // false for NaN, like box_ops.py:59
-}
-
-// matcher.py:84-90 and box_ops.py:32-45, 61-69 for one (query, target) pair.
-// `wcls` is cost_class * class cost.
-__device__ __forceinline__ float pair_cost(const PredBox &p, const TgtRec &g, float wcls, float w_bbox, float w_giou)
-{
-    const float l1 = ((fabsf(p.cx - g.cx) + fabsf(p.cy - g.cy)) + fabsf(p.w - g.w)) + fabsf(p.h - g.h);
-    const float iw = fast_max(fast_min(p.x1, g.x1) - fast_max(p.x0, g.x0), 0.0f);
-    const float ih = fast_max(fast_min(p.y1, g.y1) - fast_max(p.y0, g.y0), 0.0f);
-    const float inter = iw * ih;
-    const float uni = (p.area + g.area) - inter;
-    // enclosing box: never negative for valid boxes, so the reference's clamp is a no-op
-    const float ew = fast_max(p.x1, g.x1) - fast_min(p.x0, g.x0);
-    const float eh = fast_max(p.y1, g.y1) - fast_min(p.y0, g.y0);
-    const float earea = ew * eh;
-    // -giou = -(inter/uni - (earea - uni)/earea) = (1 - inter/uni) - uni/earea
-    const float neg_giou = __builtin_fmaf(-uni, __builtin_amdgcn_rcpf(earea),
-                                          __builtin_fmaf(-inter, __builtin_amdgcn_rcpf(uni), 1.0f));
-    return __builtin_fmaf(w_bbox, l1, __builtin_fmaf(w_giou, neg_giou, wcls));
-}
-
-// One target, validated and pre-converted, into its LDS record.
-__device__ __forceinline__ void store_target(TgtRec *slot, const float4 gb, long long l, int C, int32_t *status)
-{
-    TgtRec g;
-    g.cx = gb.x; g.cy = gb.y; g.w = gb.z; g.h = gb.w;
-    g.x0 = g.cx - 0.5f * g.w; g.y0 = g.cy - 0.5f * g.h;
-    g.x1 = g.cx + 0.5f * g.w; g.y1 = g.cy + 0.5f * g.h;
-    g.area = (g.x1 - g.x0) * (g.y1 - g.y0);
-    if (!((g.x1 >= g.x0) && (g.y1 >= g.y0))) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
-    if (l < -(long long)C || l >= (long long)C) { dm::raise_status(status, DM_ST_LABEL_RANGE); l = 0; }
-    if (l < 0) l += C;   // python-style negative index
-    g.label = (int)l; g.pad0 = 0; g.pad1 = 0;
-    *slot = g;
-}
 
 // Stage targets [tc, tc + nt) of the image in LDS (validated, pre-converted).
 __device__ __forceinline__ void stage_targets(TgtRec *tg, const int64_t *__restrict__ labels,
@@ -189,14 +84,14 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
     // own prediction boxes and logits (clamped to the last query when past the end); the
     // reference validates every prediction of the batch
     float4 raw[QPT];
-    float x[QPT][C];
+    float x[QPT][4];
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
         const size_t row = (size_t)b * Q + min(q0 + i, Q - 1);
         raw[i] = reinterpret_cast<const float4 *>(set.boxes)[row];
         const float *lg = set.logits + row * (size_t)C;
 #pragma unroll
-        for (int c = 0; c < C; ++c) x[i][c] = lg[c];
+        for (int c = 0; c < 4; ++c) x[i][c] = c < C ? lg[c] : 0.0f;
     }
     if (T > 0) stage_targets(tg, labels, tboxes, t0, min(TCHUNK, T), C, status);
 
@@ -211,23 +106,9 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
     if (T <= 0) return;
 
     // cost_class * class cost of every class, once per query
-    float wc[QPT][C];
+    float wc[QPT][4];
 #pragma unroll
-    for (int i = 0; i < QPT; ++i) {
-        if (prm.cls_mode == 0) {
-            float mx = x[i][0];
-#pragma unroll
-            for (int c = 1; c < C; ++c) mx = fmaxf(mx, x[i][c]);
-            float e[C], den = 0.0f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { e[c] = expf(x[i][c] - mx); den += e[c]; }
-#pragma unroll
-            for (int c = 0; c < C; ++c) wc[i][c] = prm.w_class * (-(e[c] / den));
-        } else {
-#pragma unroll
-            for (int c = 0; c < C; ++c) wc[i][c] = prm.w_class * focal_cost(x[i][c], prm.focal_alpha, prm.focal_gamma);
-        }
-    }
+    for (int i = 0; i < QPT; ++i) small_class_costs(x[i], C, prm, wc[i]);
 
     const int qs = set.q_stride;
     float *out = cost + set.cost_off + (size_t)t0 * qs + q0;

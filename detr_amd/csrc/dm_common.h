@@ -109,4 +109,12 @@ __device__ __forceinline__ void raise_status(int32_t *status, int bits)
     atomicOr(status, bits);
 }
 
+struct FusedIn;
+int check_hip(hipError_t e, const char *what);
+int lap_plan(const DmSet *sets, int S, int B, int max_T, unsigned char *needs_cost);
+bool lap_can_fuse(int C, int max_T);
+int lap_run(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off, const int32_t *order,
+            int max_T, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out, int32_t *status, hipStream_t st,
+            const FusedIn *fin, float *cost_w);
+
 }  // namespace dm

@@ -21,12 +21,18 @@
 //   lap_generic_kernel     any shape up to 4096 x 4096 (also T >= Q, where scipy does
 //                          not transpose): literal list-order scan with all state in LDS.
 // The first rows of a cost block are staged in LDS by LDS-DMA.
+// FUSED variants of the two register kernels do not read a cost block at all: every thread computes
+// the entries of its own columns (queries) from the predictions and the image's targets -- the
+// arithmetic of the cost kernel (cost_math.h), bit for bit -- straight into LDS; rows that do not fit
+// there go to the problem's region of the cost workspace and are read back by the thread that wrote them.
 #include <algorithm>
 #include <initializer_list>
+#include <mutex>
+#include <vector>
 #include <type_traits>
 #include <utility>
 
-#include "dm_common.h"
+#include "cost_math.h"
 
 namespace dm {
 int check_hip(hipError_t e, const char *what);
@@ -467,8 +473,9 @@ __device__ __forceinline__ unsigned long long narrow_to_minimum(unsigned long lo
 // nothing finite left) and its lane masks live in scalar registers: half of a step's instructions
 // used to be scalar control flow.  flat_out (optional): target index + tgt_off[image].
 // WIDE: compiled for up to 1024 threads whatever NCOL (the register budget of 16 wavefronts).
-template <int NCOL, bool WIDE>
+template <int NCOL, bool WIDE, bool FUSED>
 __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL)) void lap_block_kernel(const DmSetArray sets, const int S,
+                                                         const dm::FusedIn fin, float *cost_w,
                                                          const float *__restrict__ cost,
                                                          const int32_t *__restrict__ tgt_off,
                                                          const int32_t *__restrict__ order,
@@ -489,6 +496,13 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     const int nc = set.Q;                 // columns = queries
     const int t0 = tgt_off[b];
     const int nr = tgt_off[b + 1] - t0;   // rows = targets
+    if (FUSED && nr == 0) {
+        // an image without targets: its predictions are still validated (the reference asserts on the whole batch)
+        bool okb = true;
+        for (int j = tid; j < nc; j += BS)
+            okb = okb && dm::pred_valid(dm::make_pred(reinterpret_cast<const float4 *>(set.boxes)[(size_t)b * nc + j]));
+        if (!okb) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+    }
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
 #ifdef DM_LAP_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -504,12 +518,15 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     int *row4col = col4row + t_cap;                         // [QCAP]
     int *pathL = row4col + QCAP;                            // [QCAP]
     int *remaining = pathL + QCAP;                          // [QCAP] list position -> column
-    float *crow = reinterpret_cast<float *>(remaining + QCAP);   // [lds_cost_floats] first rows of the block
+    dm::TgtRec *tg = reinterpret_cast<dm::TgtRec *>(remaining + QCAP);     // FUSED: [t_cap] the image's targets
+    float *crow = FUSED ? reinterpret_cast<float *>(tg + t_cap)
+                        : reinterpret_cast<float *>(remaining + QCAP);   // [lds_cost_floats] first rows of the block
 
     const int qs = set.q_stride;
-    const float *cg = cost + set.cost_off + (size_t)t0 * qs;
+    // FUSED: the rows beyond LDS live in the workspace, written and read by the same thread
+    const float *cg = (FUSED ? cost_w : cost) + set.cost_off + (size_t)t0 * qs;
     // rows resident in LDS keep the global row stride when they can be copied linearly
-    const bool linear = (qs & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0;
+    const bool linear = FUSED || ((qs & 3) == 0 && (reinterpret_cast<uintptr_t>(cg) & 15) == 0);
     const int ls = linear ? qs : nc;                        // LDS row stride
     const int R = min(nr, lds_cost_floats / ls);            // rows resident in LDS
 
@@ -534,7 +551,10 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     // registers, every piece in flight at once); anything else through registers.
     const int nfl = R * ls;
     bool bad = false;
-    if (linear) {
+    if (FUSED) {
+        bad = dm::compute_cost_block<NCOL>(set, fin, b, nc, nr, t0, tid, BS, tg, crow, ls, R,
+                                           cost_w + set.cost_off + (size_t)t0 * qs, qs, status);
+    } else if (linear) {
         for (int base = wave * 256; base < nfl; base += W * 256) {
             const int e = base + lane * 4;
             if (e < nfl)
@@ -596,7 +616,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                     const float *row = cg + (size_t)i * qs;
 #pragma unroll
                     for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
-                    if (i == cur) {     // the only full read of a row that is not resident: validate it here
+                    if (!FUSED && i == cur) {     // the only full read of a row that is not resident: validate it here
                         bool badrow = false;
 #pragma unroll
                         for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
@@ -898,6 +918,7 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
 }
 
 constexpr int NCOL_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 15, FAST_MAX_NCOL};
+constexpr int FUSED_MAX_T = 256;      // the image's target records (48 bytes each) share LDS with the solver
 
 int ncol_class(int Q)
 {
@@ -905,43 +926,62 @@ int ncol_class(int Q)
     return 0;
 }
 
-template <int NCOL>
-int launch_wave(const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
-                int32_t *status, hipStream_t st)
+// Kernels that may need more than 64 KB of dynamic LDS get the attribute once per (function, device);
+// the record of where it has been set is shared by all host threads.
+int allow_big_lds(const void *fn, const char *what)
 {
-    const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> set_on;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &e : set_on)
+        if (e.first == fn && e.second == dev) return DM_OK;
+    int rc = dm::check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), what);
+    if (rc == DM_OK && dev >= 0) set_on.emplace_back(fn, dev);
+    return rc;
+}
+
+// Everything a launch of a register kernel needs besides its shape.
+struct LapArgs {
+    int B;
+    const float *cost;
+    const int32_t *tgt_off, *order;
+    int max_T;
+    int64_t *src_out, *tgt_out, *flat_out;
+    int32_t *status;
+    hipStream_t st;
+    const dm::FusedIn *fin;     // non-null: the kernels compute their own cost blocks ...
+    float *cost_w;              // ... and keep the rows that do not fit in LDS here
+};
+
+template <int NCOL>
+int launch_wave(const DmSetArray &arr, int n, const LapArgs &a, int max_Q, int max_stride)
+{
+    const int fast_T = a.max_T < max_Q ? a.max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const size_t fixed = (size_t)t_cap * (8 + 4 + 4) + (size_t)4 * 64 * NCOL * 4;
     size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS and keep their cost rows in
     // it; many: resident wavefronts per SIMD matter more than resident rows (measured 1.8x at 12 288
     // problems), so only the state stays in LDS and the rows are read from L2 / Infinity Cache
-    size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : fixed + 2048;
+    size_t budget = ((size_t)n * a.B <= 512) ? 80 * 1024 : fixed + 2048;
     if (g_lap_lds_kb) budget = std::max((size_t)g_lap_lds_kb * 1024, fixed + 1040);
     if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
-    // the attribute belongs to the function on ONE device: remember per device where it is set
-    static unsigned long long big_lds_devices = 0;
-    int dev = 0;
-    if (fixed + want > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && !(dev < 64 && ((big_lds_devices >> dev) & 1ull))) {
-        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_wave_kernel<NCOL>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
-                               "hipFuncSetAttribute(lap_wave_kernel)");
+    if (fixed + want > 64 * 1024) {
+        int rc = allow_big_lds(reinterpret_cast<const void *>(&lap_wave_kernel<NCOL>), "hipFuncSetAttribute(lap_wave_kernel)");
         if (rc != DM_OK) return rc;
-        if (dev < 64) big_lds_devices |= 1ull << dev;
     }
-    hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * B), dim3(64), fixed + want, st, arr, n, cost,
-                       tgt_off, order, src_out, tgt_out, flat_out, status, t_cap, (int)(want / sizeof(float)));
+    hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * a.B), dim3(64), fixed + want, a.st, arr, n, a.cost,
+                       a.tgt_off, a.order, a.src_out, a.tgt_out, a.flat_out, a.status, t_cap, (int)(want / sizeof(float)));
     return dm::check_hip(hipGetLastError(), "lap_wave_kernel launch");
 }
 
-int launch_wave_dyn(int ncol, const DmSetArray &arr, int n, int B, const float *cost, const int32_t *tgt_off,
-                    const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
-                    int32_t *status, hipStream_t st)
+int launch_wave_dyn(int ncol, const DmSetArray &arr, int n, const LapArgs &a, int max_Q, int max_stride)
 {
-#define DM_CASE(N) case N: return launch_wave<N>(arr, n, B, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, flat_out, status, st)
+#define DM_CASE(N) case N: return launch_wave<N>(arr, n, a, max_Q, max_stride)
     switch (ncol) {
         DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
         DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
@@ -969,48 +1009,42 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
 }
 
 template <int NCOL>
-int launch_block(const DmSetArray &arr, int n, int B, int waves, const float *cost, const int32_t *tgt_off,
-                 const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
-                 int32_t *status, hipStream_t st)
+int launch_block(const DmSetArray &arr, int n, const LapArgs &a, int waves, int max_Q, int max_stride)
 {
-    const int fast_T = max_T < max_Q ? max_T : max_Q - 1;     // largest row count this kernel can meet
+    const bool fused = a.fin != nullptr;
+    const int fast_T = a.max_T < max_Q ? a.max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
     const int qcap = 64 * waves * NCOL;
-    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * 16 + (size_t)3 * qcap * 4;
+    const size_t fixed = (size_t)t_cap * (8 + 4) + 32 * 16 + (size_t)3 * qcap * 4 + (fused ? (size_t)t_cap * sizeof(dm::TgtRec) : 0);
     size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS and keep their cost rows in
     // it; many: more resident workgroups beat resident rows
-    size_t budget = ((size_t)n * B <= 512) ? 80 * 1024 : std::max<size_t>(16 * 1024, fixed + 2048);
+    size_t budget = ((size_t)n * a.B <= 512) ? 80 * 1024 : std::max<size_t>(16 * 1024, fixed + 2048);
     if (g_lap_lds_kb) budget = std::max((size_t)g_lap_lds_kb * 1024, fixed + 1040);
     if (fixed + 1024 >= budget) return DM_E_UNSUPPORTED;
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
-    // the attribute belongs to the function on ONE device: remember per device where it is set
     // shapes beyond the narrow variant's thread limit use the variant compiled for 1024 threads
     constexpr int narrow_threads = NCOL == 1 ? 1024 : 64 * ((FAST_MAX_NCOL + NCOL - 1) / NCOL);
     const bool wide = 64 * waves > narrow_threads;
     if (wide && NCOL > BLOCK_MAX_NCOL_WIDE) return DM_E_UNSUPPORTED;
-    auto kernel = wide ? lap_block_kernel<NCOL, (NCOL <= BLOCK_MAX_NCOL_WIDE)> : lap_block_kernel<NCOL, false>;
-    static unsigned long long big_lds_devices[2] = {0, 0};
-    int dev = 0;
-    if (fixed + want > 64 * 1024 && hipGetDevice(&dev) == hipSuccess &&
-        !(dev < 64 && ((big_lds_devices[wide] >> dev) & 1ull))) {
-        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024),
-                               "hipFuncSetAttribute(lap_block_kernel)");
+    constexpr bool CAN_WIDE = NCOL <= BLOCK_MAX_NCOL_WIDE;
+    auto kernel = fused ? (wide ? lap_block_kernel<NCOL, CAN_WIDE, true> : lap_block_kernel<NCOL, false, true>)
+                        : (wide ? lap_block_kernel<NCOL, CAN_WIDE, false> : lap_block_kernel<NCOL, false, false>);
+    if (fixed + want > 64 * 1024) {
+        int rc = allow_big_lds(reinterpret_cast<const void *>(kernel), "hipFuncSetAttribute(lap_block_kernel)");
         if (rc != DM_OK) return rc;
-        if (dev < 64) big_lds_devices[wide] |= 1ull << dev;
     }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)n * B), dim3(64 * waves), fixed + want, st, arr, n,
-                       cost, tgt_off, order, src_out, tgt_out, flat_out, status, t_cap, (int)(want / sizeof(float)));
+    const dm::FusedIn fin = fused ? *a.fin : dm::FusedIn{};
+    hipLaunchKernelGGL(kernel, dim3((unsigned)n * a.B), dim3(64 * waves), fixed + want, a.st, arr, n, fin, a.cost_w,
+                       a.cost, a.tgt_off, a.order, a.src_out, a.tgt_out, a.flat_out, a.status, t_cap,
+                       (int)(want / sizeof(float)));
     return dm::check_hip(hipGetLastError(), "lap_block_kernel launch");
 }
 
-int launch_block_dyn(int ncol, const DmSetArray &arr, int n, int B, int waves, const float *cost,
-                     const int32_t *tgt_off, const int32_t *order, int max_T, int max_Q, int max_stride, int64_t *src_out,
-                     int64_t *tgt_out, int64_t *flat_out, int32_t *status, hipStream_t st)
+int launch_block_dyn(int ncol, const DmSetArray &arr, int n, const LapArgs &a, int waves, int max_Q, int max_stride)
 {
-#define DM_CASE(N) case N: return launch_block<N>(arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out, tgt_out, flat_out, status, st)
+#define DM_CASE(N) case N: return launch_block<N>(arr, n, a, waves, max_Q, max_stride)
     switch (ncol) {
         DM_CASE(1); DM_CASE(2); DM_CASE(3); DM_CASE(4); DM_CASE(5); DM_CASE(6); DM_CASE(8); DM_CASE(10);
         DM_CASE(12); DM_CASE(15); DM_CASE(FAST_MAX_NCOL);
@@ -1045,20 +1079,28 @@ int set_lap_knob(int knob, int value)
     }
     return DM_E_INVALID_ARG;
 }
-}  // namespace dm
 
-extern "C" int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
-                               const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
-                               int32_t *status, void *stream)
+// The launches of one call.  Every set belongs to at most one register-kernel launch (problems with
+// T < Q) and, when one of its images can have T >= Q or it has more columns than the register kernels
+// hold, to the list-order kernel as well.
+struct Launch {
+    bool block;              // workgroup-per-problem kernel (else wavefront-per-problem)
+    int ncol, waves, max_Q, max_stride;
+    std::vector<int> members;
+};
+struct Plan {
+    int fast_max_q = FAST_MAX_Q;
+    std::vector<Launch> launches;
+    std::vector<unsigned char> generic;      // [S] the list-order kernel visits this set
+    std::vector<unsigned char> fusable;      // [S] its register launch may compute the cost blocks itself
+};
+
+static int make_plan(const DmSet *sets, int S, int B, int max_T, Plan &plan)
 {
-    if (S < 0 || B < 0 || max_T < 0 || !status) return DM_E_INVALID_ARG;
-    if (S == 0 || B == 0 || max_T == 0) return DM_OK;
-    if (!sets || !cost || !tgt_off || !src_out || !tgt_out) return DM_E_INVALID_ARG;
     if (S > 4096) return DM_E_UNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     // Sets wider than the wavefront kernel's 1088 columns (up to 4096) go to the workgroup kernel when
     // it may use its widest shapes for them (16 wavefronts x at most 4 columns per thread, state
-    // within the LDS budget); otherwise the list-order kernel takes them as before.
+    // within the LDS budget); otherwise the list-order kernel takes them.
     int fast_max_q = FAST_MAX_Q;
     if ((g_lap_mode == 0 || g_lap_mode == 2) && max_T <= 1024) {
         int wide = 0, widest = 0;
@@ -1073,24 +1115,29 @@ extern "C" int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cos
             if (ncol <= BLOCK_MAX_NCOL_WIDE) fast_max_q = BLOCK_MAX_Q;
         }
     }
+    plan.fast_max_q = fast_max_q;
+    plan.generic.assign((size_t)S, 0);
+    plan.fusable.assign((size_t)S, 0);
     for (int s = 0; s < S; ++s) {
         const int Q = sets[s].Q;
         if (Q < 1 || sets[s].q_stride < Q) return DM_E_INVALID_ARG;
         const bool needs_generic = (g_lap_mode == 1) || Q > fast_max_q || max_T >= Q;
         if (needs_generic && (Q > GENERIC_MAX || max_T > GENERIC_MAX)) return DM_E_UNSUPPORTED;
+        plan.generic[(size_t)s] = needs_generic ? 1 : 0;
     }
+    if (g_lap_mode == 1) return DM_OK;
 
-    bool done[4096] = {false};
-    if (!(g_lap_mode == 1) && (g_lap_mode == 0 || g_lap_mode == 2)) {
+    std::vector<unsigned char> done((size_t)S, 0);
+    if (g_lap_mode == 0 || g_lap_mode == 2) {
         // Sets of different Q (decoder layers + a first-stage set over all encoder tokens) in ONE
         // launch shaped for the largest Q, when that does not squeeze the wavefronts per problem:
         // the kernel is latency-bound, idle lanes cost nothing, and the launches no longer queue
         // behind each other.
         int max_Q = 0, count = 0, distinct = 0;
         for (int s = 0; s < S; ++s) {
-            if (sets[s].Q > fast_max_q || max_T >= sets[s].Q) continue;
+            if (plan.generic[(size_t)s]) continue;
             bool seen = false;
-            for (int r = 0; r < s; ++r) seen |= sets[r].Q == sets[s].Q && !(sets[r].Q > fast_max_q || max_T >= sets[r].Q);
+            for (int r = 0; r < s; ++r) seen |= sets[r].Q == sets[s].Q && !plan.generic[(size_t)r];
             distinct += seen ? 0 : 1;
             max_Q = std::max(max_Q, sets[s].Q);
             ++count;
@@ -1101,63 +1148,99 @@ extern "C" int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cos
         // ... as long as all workgroups are resident at once (8192 wavefront slots on the chip)
         if (distinct > 1 && count <= DM_MAX_SETS_PER_LAUNCH && P * waves <= 8192 &&
             (max_Q <= FAST_MAX_Q || ncol <= BLOCK_MAX_NCOL_WIDE)) {
-            DmSetArray arr;
-            int n = 0, max_stride = max_Q;
+            Launch l{true, ncol, waves, max_Q, max_Q, {}};
             for (int s = 0; s < S; ++s) {
-                if (sets[s].Q > fast_max_q || max_T >= sets[s].Q) continue;
-                arr.s[n++] = sets[s];
-                done[s] = true;
-                max_stride = std::max(max_stride, sets[s].q_stride);
+                if (plan.generic[(size_t)s]) continue;
+                l.members.push_back(s);
+                done[(size_t)s] = 1;
+                plan.fusable[(size_t)s] = 1;
+                l.max_stride = std::max(l.max_stride, sets[s].q_stride);
             }
-            int rc = launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, max_Q, max_stride, src_out,
-                                      tgt_out, flat_out, status, st);
-            if (rc != DM_OK) return rc;
+            plan.launches.push_back(std::move(l));
         }
     }
-    if (!(g_lap_mode == 1)) {
-        // one launch per distinct Q among the (remaining) sets the register kernel can take
-        for (int s0 = 0; s0 < S; ++s0) {
-            const int Q = sets[s0].Q;
-            if (done[s0] || Q > fast_max_q) continue;
-            int total = 0;
-            for (int s = s0; s < S; ++s) total += (!done[s] && sets[s].Q == Q) ? 1 : 0;
-            // few problems: a workgroup of several wavefronts per problem (latency); many: one
-            // wavefront per problem (throughput)
-            int ncol = ncol_class(Q), waves = 1;
-            const long long P = (long long)total * B;
-            // crossover measured at Q=600, T~16: 20480 column slices; problems with many rows (T up to
-            // 100 at Q=900) stay faster in the workgroup kernel well beyond that
-            const long long slices = P * ((Q + 63) / 64);
-            const bool use_block = g_lap_mode == 2 || Q > FAST_MAX_Q ||
-                                   (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 20480));
-            if (use_block) pick_shape(Q, P, &ncol, &waves);
-            DmSetArray arr;
-            int n = 0, max_stride = Q;
-            for (int s = s0; s <= S; ++s) {
-                if (s < S && !done[s] && sets[s].Q == Q) {
-                    arr.s[n++] = sets[s];
-                    done[s] = true;
-                    if (sets[s].q_stride > max_stride) max_stride = sets[s].q_stride;
-                }
-                if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
-                    int rc = use_block
-                                 ? launch_block_dyn(ncol, arr, n, B, waves, cost, tgt_off, order, max_T, Q, max_stride,
-                                                    src_out, tgt_out, flat_out, status, st)
-                                 : launch_wave_dyn(ncol, arr, n, B, cost, tgt_off, order, max_T, Q, max_stride,
-                                                   src_out, tgt_out, flat_out, status, st);
-                    if (rc != DM_OK) return rc;
-                    n = 0;
-                    max_stride = Q;
-                }
+    // one launch per distinct Q among the (remaining) sets the register kernels can take; a set whose
+    // images may have T >= Q is visited by both kinds of kernel, each taking its own problems
+    for (int s0 = 0; s0 < S; ++s0) {
+        const int Q = sets[s0].Q;
+        if (done[(size_t)s0] || Q > fast_max_q) continue;
+        int total = 0;
+        for (int s = s0; s < S; ++s) total += (!done[(size_t)s] && sets[s].Q == Q) ? 1 : 0;
+        // few problems: a workgroup of several wavefronts per problem (latency); many: one
+        // wavefront per problem (throughput)
+        int ncol = ncol_class(Q), waves = 1;
+        const long long P = (long long)total * B;
+        // crossover measured at Q=600, T~16: 20480 column slices; problems with many rows (T up to
+        // 100 at Q=900) stay faster in the workgroup kernel well beyond that
+        const long long slices = P * ((Q + 63) / 64);
+        const bool use_block = g_lap_mode == 2 || Q > FAST_MAX_Q ||
+                               (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 20480));
+        if (use_block) pick_shape(Q, P, &ncol, &waves);
+        Launch l{use_block, ncol, waves, Q, Q, {}};
+        for (int s = s0; s <= S; ++s) {
+            if (s < S && !done[(size_t)s] && sets[s].Q == Q) {
+                l.members.push_back(s);
+                done[(size_t)s] = 1;
+                // the workgroup kernel can compute the set's cost blocks itself -- unless the list-order
+                // kernel needs them in memory anyway
+                plan.fusable[(size_t)s] = (use_block && !plan.generic[(size_t)s]) ? 1 : 0;
+                l.max_stride = std::max(l.max_stride, sets[s].q_stride);
+            }
+            if ((int)l.members.size() == DM_MAX_SETS_PER_LAUNCH || (s == S && !l.members.empty())) {
+                plan.launches.push_back(l);
+                l.members.clear();
+                l.max_stride = Q;
             }
         }
+    }
+    return DM_OK;
+}
+
+// For every set: does some kernel of the call read its cost blocks from memory (so that the cost
+// kernel has to run for it first)?  Only meaningful when the register kernels are allowed to compute
+// cost blocks themselves; otherwise every set needs them.
+int lap_plan(const DmSet *sets, int S, int B, int max_T, unsigned char *needs_cost)
+{
+    Plan plan;
+    int rc = make_plan(sets, S, B, max_T, plan);
+    if (rc != DM_OK) return rc;
+    for (int s = 0; s < S; ++s) needs_cost[s] = plan.fusable[(size_t)s] ? 0 : 1;
+    return DM_OK;
+}
+
+// Whether the register kernels may compute their own cost blocks for a call of this shape.
+bool lap_can_fuse(int C, int max_T) { return C >= 1 && C <= 4 && max_T <= FUSED_MAX_T; }
+
+// All assignment launches of one call.  fin != nullptr: the workgroup kernel computes the cost blocks
+// of the sets lap_plan reports as not needing them in memory (cost_w: workspace for rows beyond LDS);
+// every other kernel reads `cost`.
+int lap_run(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off, const int32_t *order,
+            int max_T, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out, int32_t *status, hipStream_t st,
+            const FusedIn *fin, float *cost_w)
+{
+    Plan plan;
+    int rc = make_plan(sets, S, B, max_T, plan);
+    if (rc != DM_OK) return rc;
+    LapArgs a{B, cost, tgt_off, order, max_T, src_out, tgt_out, flat_out, status, st, nullptr, cost_w};
+    for (const Launch &l : plan.launches) {
+        DmSetArray arr;
+        int n = 0;
+        bool fuse = fin != nullptr && l.block;
+        for (int s : l.members) {
+            arr.s[n++] = sets[s];
+            fuse = fuse && plan.fusable[(size_t)s];
+        }
+        a.fin = fuse ? fin : nullptr;
+        rc = l.block ? launch_block_dyn(l.ncol, arr, n, a, l.waves, l.max_Q, l.max_stride)
+                     : launch_wave_dyn(l.ncol, arr, n, a, l.max_Q, l.max_stride);
+        if (rc != DM_OK) return rc;
     }
 
-    // problems the register kernel does not take: T >= Q, or Q beyond its column capacity
+    // problems the register kernels do not take: T >= Q, or Q beyond their column capacity
     DmSetArray arr;
     int n = 0, max_Q = 0;
     for (int s = 0; s <= S; ++s) {
-        if (s < S && ((g_lap_mode == 1) || sets[s].Q > fast_max_q || max_T >= sets[s].Q)) {
+        if (s < S && plan.generic[(size_t)s]) {
             arr.s[n++] = sets[s];
             if (sets[s].Q > max_Q) max_Q = sets[s].Q;
         }
@@ -1169,19 +1252,32 @@ extern "C" int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cos
             const size_t lds = (size_t)c_cap * 28 + (size_t)r_cap * 12;
             if (lds > 160 * 1024) return DM_E_UNSUPPORTED;
             if (lds > 64 * 1024) {
-                int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_generic_kernel),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                                       "hipFuncSetAttribute(lap_generic_kernel)");
+                rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_generic_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                                   "hipFuncSetAttribute(lap_generic_kernel)");
                 if (rc != DM_OK) return rc;
             }
             hipLaunchKernelGGL(lap_generic_kernel, dim3((unsigned)n * B), dim3(64), lds, st, arr, n, cost, tgt_off,
-                               order, src_out, tgt_out, flat_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0, fast_max_q);
-            int rc = dm::check_hip(hipGetLastError(), "lap_generic_kernel launch");
+                               order, src_out, tgt_out, flat_out, status, c_cap, r_cap, (g_lap_mode == 1) ? 1 : 0,
+                               plan.fast_max_q);
+            rc = dm::check_hip(hipGetLastError(), "lap_generic_kernel launch");
             if (rc != DM_OK) return rc;
             n = 0; max_Q = 0;
         }
     }
     return DM_OK;
+}
+}  // namespace dm
+
+extern "C" int dm_lap_flat_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,
+                               const int32_t *order, int max_T, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
+                               int32_t *status, void *stream)
+{
+    if (S < 0 || B < 0 || max_T < 0 || !status) return DM_E_INVALID_ARG;
+    if (S == 0 || B == 0 || max_T == 0) return DM_OK;
+    if (!sets || !cost || !tgt_off || !src_out || !tgt_out) return DM_E_INVALID_ARG;
+    return dm::lap_run(sets, S, B, cost, tgt_off, order, max_T, src_out, tgt_out, flat_out, status,
+                       static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
 extern "C" int dm_lap_f32(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off,

@@ -360,12 +360,14 @@ class HungarianMatcher(torch.nn.Module):
             ws["cost"] = torch.empty(n_cost, dtype=torch.float32, device=device)
         return ws
 
-    def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False, own_buffers: bool = False):
+    def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False, own_buffers: bool = False,
+                want_cost: bool = False):
         """Enqueue the cost and assignment kernels for all output sets on the current stream.
         Returns the device index buffer, the queries per set, the cost buffer and, per set, (offset, row
         stride) of its cost region.  Index buffer: a fresh [src (S*M) | tgt (S*M) | status word (| flat
         (S*M))] that the caller may keep, or with `own_buffers` this matcher's own [status | src | tgt],
-        valid until its next call."""
+        valid until its next call.  Unless `want_cost`, the assignment kernels compute their cost blocks
+        themselves where the shapes allow it (dm_match_fused_f32) and the cost buffer is only a workspace."""
         S, batch, M = len(outputs_list), packed.batch, packed.total
         device, C, keep, queries = self._prepare_sets(outputs_list, batch)
         if packed.device != device:
@@ -403,16 +405,17 @@ class HungarianMatcher(torch.nn.Module):
             flat_ptr = status_ptr + 8 if flat else None
             self.last_status = out[2 * SM:2 * SM + 1]
         stream = torch.cuda.current_stream(device).cuda_stream
+        entry = lib.dm_match_flat_f32 if want_cost else lib.dm_match_fused_f32
         if device.index is None or device.index == torch.cuda.current_device():
-            rc = lib.dm_match_flat_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+            rc = entry(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
                                        packed.offsets_ptr, packed.order_ptr, packed.max_t, self._params_ref(),
                                        cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
         else:
             with torch.cuda.device(device):
-                rc = lib.dm_match_flat_f32(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                rc = entry(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
                                            packed.offsets_ptr, packed.order_ptr, packed.max_t, self._params_ref(),
                                            cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
-        _lib.check(rc, "dm_match_flat_f32")
+        _lib.check(rc, "dm_match_flat_f32" if want_cost else "dm_match_fused_f32")
         return out, queries, cost, strides
 
     @torch.no_grad()
@@ -439,10 +442,11 @@ class HungarianMatcher(torch.nn.Module):
             return [[] for _ in range(S)]
 
         if device_indices:
-            out, queries, cost, strides = self._launch(outputs_list, packed)
+            out, queries, cost, strides = self._launch(outputs_list, packed, want_cost=return_cost)
             result = self._split(out, S, M, sizes, queries, packed.offsets_list)
         else:
-            out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=not return_cost)
+            out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=not return_cost,
+                                                       want_cost=return_cost)
             n = 2 * S * M + 1
             host = torch.empty(n, dtype=torch.int64, pin_memory=True)
             host.copy_(out[:n], non_blocking=True)

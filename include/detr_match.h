@@ -135,6 +135,22 @@ int dm_match_flat_f32(const DmSet *sets, int S, int B, int C,
                       int32_t *status, void *stream);
 
 /*
+ * dm_match_flat_f32 as ONE kernel per group of output sets where the shapes allow it: replaces
+ * matcher.py:59-95 as a unit.  With C <= 4 logits per query and max_T <= 256, every assignment workgroup
+ * computes the cost block of its own problem (same arithmetic, same bits as dm_cost_f32) straight into
+ * LDS and solves it there; the cost matrix never travels through memory.  Sets that can meet an image
+ * with T >= Q, and calls outside those limits, take the two-kernel path of dm_match_flat_f32.  The
+ * resulting indices are identical to dm_match_flat_f32's in every case.
+ *   workspace  device, sized like `cost` of dm_match_f32; its contents after the call are unspecified
+ *              (rows of a cost block that do not fit in LDS are kept there)
+ */
+int dm_match_fused_f32(const DmSet *sets, int S, int B, int C,
+                       const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
+                       const int32_t *order, int max_T, const DmParams *params,
+                       float *workspace, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out,
+                       int32_t *status, void *stream);
+
+/*
  * dm_match_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The cost
  * blocks between the two kernels live in a fixed array of DM_NOALLOC_MAX_COST_FLOATS floats (32 MiB)
@@ -261,6 +277,7 @@ int dm_profile_read(float *cost_ms, float *lap_ms);
 #define DM_KNOB_TILE_WAVES 4     /* 4 / 8: wavefronts per workgroup in the C > 4 cost kernel */
 #define DM_KNOB_LAP_LDS_KB 5     /* 1..80: LDS budget per problem of the register assignment kernels, in KB */
 #define DM_KNOB_LAP_WAVE_BUDGET 6  /* wavefronts one launch of the workgroup-per-problem kernel may ask for */
+#define DM_KNOB_FUSE 7           /* 1: dm_match_fused_f32 takes the two-kernel path whatever the shapes */
 int dm_debug_set_knob(int knob, int value);
 
 #ifdef __cplusplus

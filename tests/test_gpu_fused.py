@@ -1,0 +1,105 @@
+"""The one-kernel path (dm_match_fused_f32: every assignment workgroup computes its own cost block)
+against the two-kernel path (cost kernel, then assignment kernel): identical indices, bit for bit,
+and the same exceptions."""
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+OK_CASES = [n for n in golden_io.case_names() if golden_io.load(n).error is None]
+
+
+def _both(matcher, sets, targets, **knobs):
+    """match_many through the fused entry (default) and with fusion switched off."""
+    import detr_amd
+
+    for k, v in knobs.items():
+        detr_amd._lib.set_knob(k, v)
+    try:
+        fused = matcher.match_many(sets, targets)
+        detr_amd._lib.set_knob("no_fuse", 1)
+        try:
+            plain = matcher.match_many(sets, targets)
+        finally:
+            detr_amd._lib.set_knob("no_fuse", 0)
+    finally:
+        for k in knobs:
+            detr_amd._lib.set_knob(k, 0)
+    return fused, plain
+
+
+def _assert_identical(fused, plain):
+    assert len(fused) == len(plain)
+    for fs, ps in zip(fused, plain):
+        assert len(fs) == len(ps)
+        for (a0, a1), (b0, b1) in zip(fs, ps):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+@pytest.mark.parametrize("name", OK_CASES)
+def test_fused_equals_two_kernel_path_on_goldens(name):
+    import detr_amd
+
+    g = golden_io.load(name)
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    for knobs in ({}, {"lap_kernel": 2}, {"lap_kernel": 3}, {"lap_lds_kb": 12}):
+        fused, plain = _both(matcher, [outputs], targets, **knobs)
+        _assert_identical(fused, plain)
+    # and the fused result is the reference's (or an equal-cost optimum)
+    for b in range(g.B):
+        gs, gt = fused[0][b][0].numpy(), fused[0][b][1].numpy()
+        rs, rt = g.indices[b]
+        if not (np.array_equal(gs, rs) and np.array_equal(gt, rt)):
+            a = golden_io.assignment_cost(g.cost[b], gs, gt)
+            r = golden_io.assignment_cost(g.cost[b], rs, rt)
+            assert abs(a - r) <= 1e-5 * max(1.0, abs(r))
+
+
+@pytest.mark.parametrize("name,batch", [("cfg1", None), ("cfg2", None), ("cfg3", None), ("cfg3_hw", None),
+                                        ("cfg3_hw2", 16), ("cfg5", None)])
+def test_fused_equals_two_kernel_path_on_workloads(name, batch):
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    fused, plain = _both(matcher, sets, targets)
+    _assert_identical(fused, plain)
+    if name in ("cfg1", "cfg2"):
+        # rows of the cost blocks that do not fit in LDS go through the workspace: same answer
+        spill, _ = _both(matcher, sets, targets, lap_lds_kb=10)
+        _assert_identical(spill, plain)
+        wave, _ = _both(matcher, sets, targets, lap_kernel=3)
+        _assert_identical(wave, plain)
+
+
+def test_fused_path_reports_the_reference_errors():
+    """Degenerate prediction boxes of an image WITHOUT targets, a label out of range, a NaN logit:
+    the fused kernels raise what the two-kernel path raises."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg2", device="cuda", batch=4)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    empty = [dict(t) for t in targets]
+    empty[2] = {"labels": targets[2]["labels"][:0], "boxes": targets[2]["boxes"][:0]}
+    bad = {k: v.clone() for k, v in sets[0].items()}
+    bad["pred_boxes"][2, 17, 2] = -0.5            # negative width in the image that has no targets
+    with pytest.raises(AssertionError):
+        matcher.match_many([bad], empty)
+    matcher.match_many([sets[0]], empty)          # the kept status word was cleared
+    lab = [dict(t) for t in targets]
+    lab[1] = {"labels": targets[1]["labels"].clone(), "boxes": targets[1]["boxes"]}
+    lab[1]["labels"][0] = 2
+    with pytest.raises(IndexError):
+        matcher.match_many([sets[0]], lab)
+    nan = {k: v.clone() for k, v in sets[0].items()}
+    nan["pred_logits"][0, 5, 1] = float("nan")
+    with pytest.raises(ValueError):
+        matcher.match_many([nan], targets)
+    ok = matcher.match_many([sets[0]], targets)
+    assert len(ok[0]) == 4

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--iters", type=int, default=200)
-    ap.add_argument("--which", default="cost,lap")
+    ap.add_argument("--which", default="cost,lap,both,fused")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-shape knob, e.g. lap_kernel=3, lap_max_waves=5, cost_tsplit=2, tile_waves=8")
     args = ap.parse_args()
@@ -94,6 +94,14 @@ def main():
             assert rc == 0, rc
         us = timeit(run_match, args.iters)
         print(f"match: {us:7.2f} us per dm_match_f32 (cost kernel in the targets' processing order)")
+    if "fused" in args.which:
+        def run_fused():
+            rc = lib.dm_match_fused_f32(arr, S, B, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
+                                        packed.offsets_ptr, packed.order_ptr, packed.max_t, ctypes.byref(prm),
+                                        cost.data_ptr(), out.data_ptr(), out.data_ptr() + 8 * S * M, None, status, stream)
+            assert rc == 0, rc
+        us = timeit(run_fused, args.iters)
+        print(f"fused: {us:7.2f} us per dm_match_fused_f32  {S * B / us:8.2f} problems/us")
     if "both" in args.which:
         def run_both():
             run_cost()
