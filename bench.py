@@ -17,7 +17,8 @@ of the path, the all-reduce of the matched-box counts (asynchronous, waited for 
 have been enqueued).
 
 Prints one JSON line: whole-job matched images/s, plus
-  roofline      cost kernel: algorithmic bytes per step / HIP-event time per step, vs 8 TB/s
+  roofline      cost kernel on this run's inputs: algorithmic bytes per launch / HIP-event time per
+                launch (back-to-back launches in a pass of its own), vs 8 TB/s
   cpu_baseline  the reference's CPU formulation (torch ops on the whole batch + scipy per
                 image, restated in oracle/torch_pipeline.py) timed on this host, rank 0, N=1.
 """
@@ -107,7 +108,7 @@ def cpu_baseline(wl, sets, targets, min_s=10.0, budget_s=20.0):
     }
 
 
-def stress_roofline(device, launches=20, workload="cfg4", copy_reference=True):
+def stress_roofline(device, launches=20, workload="cfg4", copy_reference=True, given=None):
     """Cost kernel alone, timed with two events on the launch stream around `launches` back-to-back
     launches through the C ABI (no per-launch event bracket, no other work in between).
     Default: the cfg4 size (B=256, Q=900, C=91, heavy-tail T, 6 sets: 0.65 GB of algorithmic traffic
@@ -117,7 +118,8 @@ def stress_roofline(device, launches=20, workload="cfg4", copy_reference=True):
     from detr_amd._lib import DmSet, lib
     from detr_amd.matcher import PackedTargets
 
-    wl, sets, targets = synth.make_workload(workload, device=device)
+    wl, sets, targets = given if given is not None else synth.make_workload(workload, device=device)
+    workload = wl.name
     packed = PackedTargets(targets, device)
     S, M = len(sets), packed.total
     arr = (DmSet * S)()
@@ -153,10 +155,12 @@ def stress_roofline(device, launches=20, workload="cfg4", copy_reference=True):
     del cost, sets
     kernel = "cost_small_kernel" if wl.n_logits <= 4 else "cost_tile_kernel"
     if not copy_reference:
-        return {"workload": f"{workload} cost kernel only, back-to-back launches", "bound": "hbm", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(kernel, workload), "kernel": kernel,
-                "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms}
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(kernel, workload) if packed.batch == wl.batch else None,
+                "kernel": kernel, "algorithmic_bytes_per_launch": algo, "ms_per_launch": ms, "launches": launches,
+                "what": f"dm_cost_f32 on this run's {workload} inputs: {launches} back-to-back launches between two "
+                        "HIP events on the launch stream, in a pass of its own"}
     # what a plain streaming kernel reaches on this GPU: a 1 GiB device-to-device copy (read + write)
     a = torch.empty(1 << 28, dtype=torch.float32, device=device)
     b = torch.empty_like(a)
@@ -363,9 +367,14 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        algo_bytes = cost_kernel_bytes(wl.set_queries, wl.n_logits, sizes)
-        cost_kernel_name = "cost_small_kernel" if wl.n_logits <= 4 else "cost_tile_kernel"
-        achieved = algo_bytes / (cost_ms_avg * 1e-3) / 1e9
+        fused = wl.n_logits <= 4 and max(sizes) <= 256 and all(q > max(sizes) for q in wl.set_queries)
+        # The cost kernel on this run's inputs.  When the step runs as ONE kernel (C <= 4: every assignment
+        # workgroup computes its own cost block in LDS, no cost matrix in HBM) the cost kernel is not part of
+        # the headline step any more; it is still the kernel the cost-kernel HBM figure of the metric is
+        # about, and the one that runs for C > 4, T >= Q and return_cost=True.
+        roofline = stress_roofline(device, launches=max(args.steps, 50), copy_reference=False,
+                                   given=(wl, sets, targets))
+        roofline["part_of_headline_step"] = not fused
         record = {
             "metric": "matched images/sec (Q=600, ~16 GT/img, 6 aux layers); cost-kernel HBM GB/s",
             "value": total_images * args.steps / elapsed,
@@ -385,19 +394,19 @@ def main():
                        "parallelism": f"dp{world}", "python_gc": "paused while timing (as timeit does)"},
             "with_python_gc": {"value": total_images * args.steps / elapsed_gc, "unit": "images/s",
                                "ms_per_step": 1e3 * elapsed_gc / args.steps},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(cost_kernel_name, wl.name) if B == wl.batch else None,
-                         "kernel": cost_kernel_name, "algorithmic_bytes_per_step": algo_bytes,
-                         "ms_per_step_hip_events": cost_ms_avg},
-            "lap": {"kernel": "lap_block_kernel / lap_wave_kernel", "ms_per_step_hip_events": lap_ms_avg,
-                    "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
+            "roofline": roofline,
+            "step_kernels": {"what": "HIP events on the launch stream around the kernels of every step, in a pass of "
+                                     "its own (dm_profile_*)",
+                             "one_kernel_per_step": fused,
+                             "cost_kernel_ms_per_step": cost_ms_avg,
+                             "assignment_kernel": ("lap_block_kernel<FUSED>: cost block computed in LDS + assignment"
+                                                   if fused else "lap_block_kernel / lap_wave_kernel"),
+                             "assignment_kernel_ms_per_step": lap_ms_avg,
+                             "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
         }
         if world == 1:
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
         if world == 1 and not args.no_stress:
-            record["roofline_back_to_back"] = stress_roofline(device, launches=200, workload=wl.name,
-                                                              copy_reference=False)
             record["roofline_stress"] = stress_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             record["cpu_baseline"] = cpu_baseline(wl, sets, targets)
