@@ -20,7 +20,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import DmParams, DmSet, lib
 
 Indices = List[Tuple[torch.Tensor, torch.Tensor]]
@@ -258,6 +258,10 @@ class HungarianMatcher(torch.nn.Module):
         self.focal_alpha = focal_alpha
         self.focal_gamma = focal_gamma
         self.last_status = None
+        # True: call the kernels through the registered operators torch.ops.detr_amd.* also in eager mode
+        # (they are always used while torch.compile traces); False: the same C entry points directly,
+        # which saves the operator dispatch and a fresh index buffer per call
+        self.through_ops = False
         self._events = {}
         self._buffers = {}
         self._packed = None
@@ -276,7 +280,8 @@ class HungarianMatcher(torch.nn.Module):
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None)):
+        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None),
+                            ("through_ops", False)):
             self.__dict__.setdefault(name, value)
 
     def _done_event(self, device) -> torch.cuda.Event:
@@ -307,29 +312,8 @@ class HungarianMatcher(torch.nn.Module):
 
     @staticmethod
     def _prepare_sets(outputs_list, batch: int):
-        logits0 = outputs_list[0]["pred_logits"]
-        device, C = logits0.device, int(logits0.shape[-1])
-        if device.type != "cuda":
-            raise RuntimeError("detr_amd.HungarianMatcher runs on the GPU only (got tensors on %s)" % device)
-        keep, dims = [], []
-        for out in outputs_list:
-            logits, boxes = out["pred_logits"], out["pred_boxes"]
-            if logits.dim() != 3 or boxes.dim() != 3 or boxes.shape[-1] != 4:
-                raise ValueError("pred_logits must be [B, Q, C] and pred_boxes [B, Q, 4]")
-            if logits.shape[0] != batch or boxes.shape[0] != batch or logits.shape[1] != boxes.shape[1]:
-                raise ValueError("pred_logits / pred_boxes / targets disagree on batch size or query count")
-            if int(logits.shape[-1]) != C:
-                raise ValueError("all output sets of one call must share the class dimension")
-            if logits.dtype != torch.float32 or boxes.dtype != torch.float32:
-                raise RuntimeError(f"predictions must be float32, got {logits.dtype} / {boxes.dtype}")
-            if logits.device != device or boxes.device != device:
-                raise ValueError("all output sets must be on the same device")
-            logits, boxes = logits.contiguous(), boxes.contiguous()
-            if boxes.data_ptr() % 16:
-                boxes = boxes.clone()
-            keep.append((logits, boxes))
-            dims.append(int(logits.shape[1]))
-        return device, C, keep, dims
+        return ops.check_predictions([o["pred_logits"] for o in outputs_list],
+                                     [o["pred_boxes"] for o in outputs_list], batch)
 
     def _packed_for(self, targets, device) -> PackedTargets:
         """The packed form of `targets`; the previous call's when these are the same unchanged tensors
@@ -369,24 +353,22 @@ class HungarianMatcher(torch.nn.Module):
         valid until its next call.  Unless `want_cost`, the assignment kernels compute their cost blocks
         themselves where the shapes allow it (dm_match_fused_f32) and the cost buffer is only a workspace."""
         S, batch, M = len(outputs_list), packed.batch, packed.total
+        if self.through_ops or torch.compiler.is_compiling():
+            # the same entry points as registered operators (detr_amd/ops.py): what tracing sees
+            logits_list = [o["pred_logits"] for o in outputs_list]
+            boxes_list = [o["pred_boxes"] for o in outputs_list]
+            prm = (0 if self.cls_loss == "ce" else 1, float(self.cost_class), float(self.cost_bbox),
+                   float(self.cost_giou), float(self.focal_alpha), float(self.focal_gamma))
+            common = (logits_list, boxes_list, packed.labels, packed.boxes, packed.meta, M, packed.max_t) + prm
+            out = ops.match(*common, flat)
+            queries = [int(l.shape[1]) for l in logits_list]
+            cost = ops.cost(*common) if want_cost else None
+            self.last_status = out[2 * S * M:2 * S * M + 1]
+            return out, queries, cost, ops.set_array(None, queries, M)[2]
         device, C, keep, queries = self._prepare_sets(outputs_list, batch)
         if packed.device != device:
             raise ValueError("targets and predictions must be on the same device")
-        sets = (DmSet * S)()
-        cost_off = 0
-        strides = []
-        for s in range(S):
-            logits, boxes = keep[s]
-            q = queries[s]
-            if q == 0:
-                raise ValueError("an output set has no queries")
-            stride = (q + 31) & ~31          # rows start on 128-byte lines
-            d = sets[s]
-            d.logits, d.boxes = logits.data_ptr(), boxes.data_ptr()
-            d.cost_off, d.out_off = cost_off, s * M
-            d.Q, d.q_stride = q, stride
-            strides.append((cost_off, stride))
-            cost_off += M * stride
+        sets, cost_off, strides = ops.set_array(keep, queries, M)
 
         SM = S * M
         if own_buffers:
@@ -445,25 +427,25 @@ class HungarianMatcher(torch.nn.Module):
             out, queries, cost, strides = self._launch(outputs_list, packed, want_cost=return_cost)
             result = self._split(out, S, M, sizes, queries, packed.offsets_list)
         else:
-            out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=not return_cost,
-                                                       want_cost=return_cost)
+            own = not (return_cost or self.through_ops or torch.compiler.is_compiling())
+            out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=own, want_cost=return_cost)
             n = 2 * S * M + 1
             host = torch.empty(n, dtype=torch.int64, pin_memory=True)
             host.copy_(out[:n], non_blocking=True)
             done = self._done_event(device)
             done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
             # the per-image views depend on shapes only: build them while the GPU is working
-            if return_cost:
-                result, status_at = self._split(host, S, M, sizes, queries, packed.offsets_list), n - 1
-            else:
+            if own:
                 result, status_at = self._split(host[1:], S, M, sizes, queries, packed.offsets_list), 0
+            else:
+                result, status_at = self._split(host, S, M, sizes, queries, packed.offsets_list), n - 1
             # by now the copy has normally landed: one event query is several times cheaper than a
             # stream synchronisation, which is only the fallback
             if not done.query():
                 done.synchronize()
             bits = int(host[status_at]) & 0xFFFFFFFF
             if bits:
-                if not return_cost:
+                if own:
                     out[:1].zero_()          # the kept buffer's status word, for the next call
                 _raise_for_status(bits)
         if return_cost:
