@@ -43,20 +43,19 @@ __device__ __forceinline__ float pow_gamma(float x, float gamma)
     return powf(x, gamma);
 }
 
-// matcher.py:76-81 for one logit.
-// sigmoid and its complement are formed from a = exp(-|x|) as 1/(1+a) and a/(1+a): the
-// complement keeps full relative accuracy where the reference's fp32 `1 - p` has lost it
-// (it stays within one rounding of p of the reference's value); exp and log are the
-// hardware v_exp_f32 / v_log_f32 (1 ulp).
+// matcher.py:76-81 for one logit, in the reference's own form: p = 1 / (1 + exp(-x)) rounded to fp32,
+// then 1 - p from that rounded p (NOT the exactly complementary sigmoid(-x): for x > 9 the reference's
+// log(1 - p + 1e-8) is a function of the last bits of p, up to p == 1 for x > 16.6, and the assignment
+// has to see the same cost).  exp, reciprocal and log are the hardware v_exp_f32 / v_rcp_f32 /
+// v_log_f32 (1 ulp each): p lands within a few ulp of torch's, like torch's own CPU and GPU kernels
+// differ from one another.
 // G2: gamma == 2 is known at compile time (keeps the general powf out of the instruction stream).
 template <bool G2 = false>
 __device__ __forceinline__ float focal_cost(float x, float alpha, float gamma)
 {
-    const float a = __builtin_amdgcn_exp2f(-fabsf(x) * 1.44269504088896f);
-    const float big = __builtin_amdgcn_rcpf(1.0f + a);     // sigmoid(|x|)
-    const float small = a * big;                            // sigmoid(-|x|)
-    const float p = x >= 0.0f ? big : small;
-    const float q = x >= 0.0f ? small : big;                // 1 - p
+    const float a = __builtin_amdgcn_exp2f(x * -1.44269504088896f);     // exp(-x); +inf for x < -88.7: p = 0
+    const float p = __builtin_amdgcn_rcpf(1.0f + a);
+    const float q = 1.0f - p;
     const float nlog_q = -(__builtin_amdgcn_logf(q + 1e-8f) * 0.693147180559945f);
     const float nlog_p = -(__builtin_amdgcn_logf(p + 1e-8f) * 0.693147180559945f);
     const float neg = ((1.0f - alpha) * (G2 ? p * p : pow_gamma(p, gamma))) * nlog_q;

@@ -109,6 +109,19 @@ def build_cases():
     c["pboxes"][:, 60:] = 0.0
     cases["masked_first_stage"] = c
 
+    # the stress shapes: a slice of the COCO-like workload (91 classes, 900 queries, up to 100 targets) ...
+    cases["focal_c91_q900_t100"] = regular_case(55, "focal", 91, 91, 4, 900, [0, 3, 64, 100], (2.0, 5.0, 2.0))
+    # ... a first stage over all 25 x 42 encoder tokens, the padded ones masked to (0, 0, 0, 0) ...
+    c = regular_case(56, "focal", 2, 2, 2, 1050, [12, 30], (2.0, 5.0, 2.0))
+    c["pboxes"][0, 800:] = 0.0
+    c["pboxes"][1, 1000:] = 0.0
+    cases["focal_c2_q1050_first_stage"] = c
+    # ... and saturated logits (sigma = 8): sigmoid(x) rounds to 0 or 1 for many entries, the regime in which
+    # the reference's log(1 - p + 1e-8) depends on the last bit of p
+    c = regular_case(57, "focal", 2, 2, 2, 100, [9, 14], (2.0, 5.0, 2.0))
+    c["logits"] *= 4.0
+    cases["focal_c2_saturated"] = c
+
     # error cases: the reference must raise
     c = regular_case(61, "ce", 3, 2, 2, 30, [4, 3], (2.0, 5.0, 2.0))
     c["logits"][1, 7, 1] = float("nan")

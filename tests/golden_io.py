@@ -71,7 +71,10 @@ def assignment_cost(cost_qt, src, tgt):
 # --------------------------------------------------------------------------------------
 # cost tolerance
 # --------------------------------------------------------------------------------------
-COST_RTOL, COST_ATOL = 1e-5, 1e-6
+# 1e-5 relative to max(|cost|, 1): the terms of an entry (5 * L1, 2 * class, 2 * GIoU, each of order one to
+# ten) can cancel to a total near zero, and two correct fp32 evaluations then differ by ulps of the terms, not
+# of the total (observed between the reference's torch ops and a plain C restatement: 5.7e-6 on a total of 0.06)
+COST_RTOL, COST_ATOL = 1e-5, 1e-5
 
 
 def _focal64_from_p(p, alpha, gamma):
@@ -93,18 +96,41 @@ def focal_sensitivity(logits_qc, labels, alpha, gamma, ulps=2.0):
     return np.abs(_focal64_from_p(hi, alpha, gamma) - _focal64_from_p(lo, alpha, gamma))
 
 
-def assert_cost_close(got_qt, ref_qt, logits_qc, labels, cls_loss, w_class, alpha, gamma):
-    """The north-star bar -- 1e-5 relative in fp32 -- widened, for the focal class term only,
-    by that term's own sensitivity to a 2-ulp change of sigmoid(x)."""
+# |x| beyond which the last bits of sigmoid(x) can move the focal class term past the plain bar: one ulp of p
+# (6e-8) changes cost_class * (1 - alpha) * p^2 * log(1 - p + 1e-8) by 2 * 0.75 * 6e-8 * e^x = 4.9e-6 at x = 4
+# and 1.8e-6 at x = 3, and two correct fp32 evaluations of sigmoid (torch's vectorised CPU kernel, libm, the
+# GPU's exp / reciprocal instructions) differ by up to 4 ulp from one another
+SENSITIVE_LOGIT = 3.0
+
+
+def assert_cost_close(got_qt, ref_qt, logits_qc, labels, cls_loss, w_class, alpha, gamma, stats=None):
+    """The north-star bar -- 1e-5 relative in fp32.  Only for focal entries whose logit is saturated
+    (|x| > 3) the bar is widened by the class term's own sensitivity to a 2-ulp change of sigmoid(x).
+    Returns the share of ALL entries inside the plain bar; `stats` (a dict) receives that share, the
+    worst relative error among the unsaturated entries and the number of saturated ones."""
     got = np.asarray(got_qt, dtype=np.float64)
     ref = np.asarray(ref_qt, dtype=np.float64)
     assert got.shape == ref.shape
-    tol = COST_RTOL * np.abs(ref) + COST_ATOL
+    plain = COST_RTOL * np.abs(ref) + COST_ATOL
+    tol = plain
+    saturated = np.zeros(ref.shape, dtype=bool)
     if cls_loss != "ce" and ref.size:
-        tol = tol + abs(w_class) * focal_sensitivity(logits_qc, labels, alpha, gamma)
+        x = np.asarray(logits_qc, dtype=np.float64)[:, np.asarray(labels, dtype=np.int64)]
+        saturated = np.abs(x) > SENSITIVE_LOGIT
+        tol = plain + np.where(saturated, abs(w_class) * focal_sensitivity(logits_qc, labels, alpha, gamma), 0.0)
     err = np.abs(got - ref)
     bad = ~(err <= tol)
     assert not bad.any(), "cost mismatch: %d of %d entries, worst |err| %.3e (tol %.3e)" % (
         bad.sum(), bad.size, err[bad].max(), tol[bad][np.argmax(err[bad])])
-    strict = err <= COST_RTOL * np.abs(ref) + COST_ATOL
-    return float(strict.mean()) if ref.size else 1.0
+    strict = err <= plain
+    share = float(strict.mean()) if ref.size else 1.0
+    if stats is not None:
+        rel = err / np.maximum(np.abs(ref), COST_ATOL / COST_RTOL)
+        stats["entries"] = stats.get("entries", 0) + int(ref.size)
+        stats["inside_plain_bar"] = stats.get("inside_plain_bar", 0) + int(strict.sum())
+        stats["saturated_entries"] = stats.get("saturated_entries", 0) + int(saturated.sum())
+        unsat = rel[~saturated]
+        stats["worst_rel_err_unsaturated"] = max(stats.get("worst_rel_err_unsaturated", 0.0),
+                                                 float(unsat.max()) if unsat.size else 0.0)
+        stats["worst_rel_err_all"] = max(stats.get("worst_rel_err_all", 0.0), float(rel.max()) if rel.size else 0.0)
+    return share

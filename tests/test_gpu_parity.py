@@ -42,17 +42,43 @@ def _assert_same_or_equal_cost(cost_qt, got, ref):
     return False
 
 
+PARITY_REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_parity_report():
+    """Per golden case: share of cost entries inside the plain 1e-5 bar and the worst relative error, written
+    where the GPU run's artefacts go (copied to profiles/ by hand when they are to be kept)."""
+    yield
+    if PARITY_REPORT:
+        import json
+        import os
+
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(PARITY_REPORT, f, indent=1, sort_keys=True)
+
+
 @pytest.mark.parametrize("name", OK_CASES)
 def test_golden_costs(name):
     g = golden_io.load(name)
     outputs, targets = g.torch_inputs("cuda")
     blocks = _matcher(**g.matcher_kwargs()).cost_blocks(outputs, targets)
+    stats = {}
     for b in range(g.B):
         got = blocks[b].cpu().numpy()
         assert got.shape == (g.Q, g.sizes[b])
-        strict = golden_io.assert_cost_close(got, g.cost[b], g.logits[b], g.labels[b], g.cls_loss,
-                                             g.weights[0], g.alpha, g.gamma)
-        assert strict >= 0.98       # share of entries inside the plain 1e-5 relative bar
+        golden_io.assert_cost_close(got, g.cost[b], g.logits[b], g.labels[b], g.cls_loss,
+                                    g.weights[0], g.alpha, g.gamma, stats)
+    if stats.get("entries"):
+        stats["share_inside_plain_bar"] = stats["inside_plain_bar"] / stats["entries"]
+        PARITY_REPORT[name] = stats
+        # every entry whose logit is not saturated meets the plain 1e-5 bar (assert_cost_close widens the bar
+        # for saturated ones only); over all entries the share stays above 99.8 % (lowest observed: 99.90 %,
+        # focal_c2_q1050_first_stage) except in the case that was built to be saturated
+        assert stats["inside_plain_bar"] >= stats["entries"] - stats["saturated_entries"]
+        assert stats["share_inside_plain_bar"] >= (0.9 if name == "focal_c2_saturated" else 0.998)
 
 
 @pytest.mark.parametrize("name", OK_CASES)
@@ -198,6 +224,12 @@ def test_workload_cfg1_full():
 
 def test_workload_cfg2_full():
     exact, total = _check_workload("cfg2")
+    assert exact >= 0.99 * total
+
+
+def test_workload_cfg3_full():
+    """cfg3 as stated: B=64, six decoder sets and the two-stage encoder set, all at Q=300."""
+    exact, total = _check_workload("cfg3")
     assert exact >= 0.99 * total
 
 
