@@ -121,5 +121,7 @@ def check(rc, what):
     if rc == E_LAUNCH:
         msg += ": " + lib.dm_last_hip_error().decode()
     if rc == E_UNSUPPORTED:
-        raise NotImplementedError(f"{what}: {msg}")
+        raise NotImplementedError(
+            f"{what}: {msg} (B <= 65535 images, S <= 4096 sets, C <= 611 classes (627 with the focal class cost), "
+            "Q and T <= 4096 per problem; see include/detr_match.h)")
     raise RuntimeError(f"{what}: {msg}")

@@ -94,13 +94,21 @@ def matched_box_losses(outputs_list, flats: Sequence[FlatMatches]) -> List[Tuple
 
 
 def matched_box_loss_total(outputs_list, flats: Sequence[FlatMatches], l1_weight: float = 1.0,
-                           giou_weight: float = 1.0) -> torch.Tensor:
-    """sum over the output sets of `l1_weight * l1_loss + giou_weight * giou_loss` -- the box part of
-    the reference's total loss (loss.py:135-160 adds the per-layer losses with these weights) --
-    as one scalar with two autograd nodes instead of a dozen per set."""
+                           giou_weight: float = 1.0, reduction: str = "mean") -> torch.Tensor:
+    """`l1_weight * l1_loss + giou_weight * giou_loss` over the output sets as one scalar with two
+    autograd nodes instead of a dozen per set.
+
+    reduction='mean' (default): the MEAN over the sets -- the box part of the reference's total loss when
+    `outputs_list` holds the sets of ONE output group (`calc_total_loss` takes the mean of the per-layer
+    losses of each key before weighting them, /root/reference/models/detr/loss.py:150-154; call it once per
+    key for `'model'` and `'first_stage'`).  reduction='sum': the plain sum over the sets, len(flats) times
+    the mean."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError("reduction must be 'mean' or 'sum'")
     sums = _PairLossSums.apply(list(flats), *[o["pred_boxes"] for o in outputs_list])
-    scale = torch.tensor([[l1_weight / max(f.num_matched, 1), giou_weight / max(f.num_matched, 1)] for f in flats],
-                         dtype=torch.float32).to(sums.device, non_blocking=True)
+    share = 1.0 / max(len(flats), 1) if reduction == "mean" else 1.0
+    scale = torch.tensor([[share * l1_weight / max(f.num_matched, 1), share * giou_weight / max(f.num_matched, 1)]
+                          for f in flats], dtype=torch.float32).to(sums.device, non_blocking=True)
     return (sums * scale).sum()
 
 

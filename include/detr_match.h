@@ -93,6 +93,8 @@ int dm_device_count(void);
  *   status   device int32[1], OR-ed with DM_ST_LABEL_RANGE / DM_ST_DEGENERATE_BOX
  * Prediction boxes of every image are validated, also of images without targets,
  * as the reference's batch-wide assert does.
+ * Limits (DM_E_UNSUPPORTED beyond): B <= 65535 images, S <= 4096 sets, and for C > 4 a tile of 64 logit rows
+ * must fit in LDS: 64 * C * 4 bytes + 3 KB (+ 4 KB with cls_mode 0) <= 160 KB, i.e. C <= 627 (611).
  */
 int dm_cost_f32(const DmSet *sets, int S, int B, int C,
                 const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,

@@ -104,7 +104,9 @@ def test_all_sets_of_a_step_against_torch_autograd(name, batch):
     # the weighted total in one scalar gives the same value and gradients
     for o in sets:
         o["pred_boxes"].grad = None
-    one = losses.matched_box_loss_total(sets, flats, 5.0, 2.0)
+    mean = losses.matched_box_loss_total(sets, flats, 5.0, 2.0)      # the reference's mean over the layers
+    assert _close(mean.item(), total.item() / len(sets))
+    one = losses.matched_box_loss_total(sets, flats, 5.0, 2.0, reduction="sum")
     assert _close(one.item(), total.item())
     one.backward()
     for s, o in enumerate(sets):

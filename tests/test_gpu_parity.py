@@ -375,3 +375,23 @@ def test_device_indices_mode_matches_cpu_mode():
         for (a0, a1), (b0, b1) in zip(cpu[s], dev[s]):
             assert b0.device.type == "cuda"
             assert torch.equal(a0, b0.cpu()) and torch.equal(a1, b1.cpu())
+
+
+def test_tensors_on_a_device_that_is_not_current():
+    """Predictions and targets on cuda:1 while cuda:0 is the current device: the kernels, the copy and the
+    completion event all go to the tensors' device (needs two GPUs)."""
+    import detr_amd
+    from detr_amd import synth
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    wl, sets, targets = synth.make_workload("cfg2", device="cpu", batch=8)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    here = matcher.match_many([{k: v.cuda(0) for k, v in s.items()} for s in sets],
+                              [{k: v.cuda(0) for k, v in t.items()} for t in targets])
+    torch.cuda.set_device(0)
+    there = matcher.match_many([{k: v.cuda(1) for k, v in s.items()} for s in sets],
+                               [{k: v.cuda(1) for k, v in t.items()} for t in targets])
+    for s in range(len(sets)):
+        for (a0, a1), (b0, b1) in zip(here[s], there[s]):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)

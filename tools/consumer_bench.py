@@ -56,7 +56,7 @@ def fused_way(sets, flats, no_object):
 
 def fused_total(sets, flats, no_object):
     losses.target_class_maps(flats, no_object)
-    losses.matched_box_loss_total(sets, flats, 5.0, 2.0).backward()
+    losses.matched_box_loss_total(sets, flats, 5.0, 2.0, reduction="sum").backward()
 
 
 def timeit(fn, n=50):
