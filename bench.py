@@ -40,7 +40,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
 
 
 def measured_traffic(kernel, workload):
@@ -402,6 +402,8 @@ def main():
                              "assignment_kernel": ("lap_block_kernel<FUSED>: cost block computed in LDS + assignment"
                                                    if fused else "lap_block_kernel / lap_wave_kernel"),
                              "assignment_kernel_ms_per_step": lap_ms_avg,
+                             "assignment_kernel_traffic_bytes": (measured_traffic("lap_block_kernel", wl.name)
+                                                                 if fused and B == wl.batch else None),
                              "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
         }
         if world == 1:

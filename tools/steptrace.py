@@ -33,6 +33,7 @@ for it in range(N + 20):
     if os.environ.get("SYNC_BEFORE_SPLIT"):
         torch.cuda.current_stream(dev).synchronize()
     t3 = time.perf_counter()
+    res = None          # (drop the previous step's tuples first, as `indices = matcher(...)` does not: see below)
     res = m._split(host[1:], S, packed.total, packed.sizes, queries, packed.offsets_list)
     t4 = time.perf_counter()
     if EV is not None:
