@@ -40,7 +40,7 @@ class DmParams(ctypes.Structure):
 
 
 #: every symbol include/detr_match.h declares
-EXPORTS = ["dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
+EXPORTS = ["dm_pack_targets", "dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_noalloc_f32",
            "dm_profile_enable", "dm_profile_read",
            "dm_debug_set_knob",
@@ -63,7 +63,10 @@ def _load():
     lib.dm_last_hip_error.argtypes = []
     lib.dm_device_count.restype = ctypes.c_int
     lib.dm_device_count.argtypes = []
-    setp, prmp = ctypes.POINTER(DmSet), ctypes.POINTER(DmParams)
+    # (the set descriptors are passed as a ctypes array of DmSet or as bytes holding the same records)
+    setp, prmp = ctypes.c_void_p, ctypes.c_void_p
+    lib.dm_pack_targets.restype = ctypes.c_int
+    lib.dm_pack_targets.argtypes = [ctypes.c_char_p, ctypes.c_char_p, i32, vp, vp, vp, vp]
     lib.dm_cost_f32.restype = ctypes.c_int
     lib.dm_cost_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, i32, prmp, vp, vp, vp]
     lib.dm_lap_f32.restype = ctypes.c_int

@@ -13,9 +13,17 @@
 //     one is made, finds the objects of the call before that free.  An object that is still
 //     referenced anywhere -- Python reference, C++ reference, weak reference -- is never touched; a
 //     fresh one takes its place in the pool.
+//
+// The module also has the two per-tensor scans of a matcher call (scan_targets, scan_outputs): with 64
+// images and 6 output sets a call touches 140 tensors, and checking dtype / device / layout and taking
+// the data pointer of each costs more in the interpreter (about 0.3 us per tensor) than the GPU spends
+// per image.  They only read tensor metadata; anything unusual (other dtypes, non-contiguous tensors,
+// mismatched lengths) is reported as None and the Python code takes its general path, which raises the
+// reference's exceptions.
 // No GPU code here; the kernels are in the .hip files.
 #include <Python.h>
 
+#include <algorithm>
 #include <vector>
 
 #include <ATen/core/Tensor.h>
@@ -157,7 +165,184 @@ PyObject *clear_pool(PyObject *, PyObject *)
     Py_RETURN_NONE;
 }
 
+// Borrowed reference to d[key] if d is a dict and the value is a tensor, else nullptr.
+const at::Tensor *dict_tensor(PyObject *d, PyObject *key)
+{
+    if (!PyDict_Check(d)) return nullptr;
+    PyObject *v = PyDict_GetItemWithError(d, key);
+    if (!v) { PyErr_Clear(); return nullptr; }
+    if (!THPVariable_Check(v)) return nullptr;
+    return &THPVariable_Unpack(v);
+}
+
+PyObject *g_key_labels = nullptr, *g_key_boxes = nullptr, *g_key_logits = nullptr, *g_key_pboxes = nullptr;
+
+// scan_targets(targets, device_index) -> None, or
+//   (sizes: list[int], total: int, max_t: int, pointers: bytes, tensors: list, versions: bytes,
+//    offsets: list[int] (B + 1 exclusive prefix sums), meta: bytes (int32 offsets (B + 1) | processing order (B)))
+// pointers: per image (labels data pointer, boxes data pointer) as two uint64; tensors: labels_0, boxes_0,
+// labels_1, ... (kept by the caller: the pointers stay valid and a later call can be compared with them);
+// versions: their version counters as uint32.  None unless every image has int64 1-D contiguous labels and
+// float32 [T, 4] contiguous boxes of equal length on CUDA device `device_index`.
+PyObject *scan_targets(PyObject *, PyObject *args)
+{
+    PyObject *targets;
+    long device_index;
+    if (!PyArg_ParseTuple(args, "Ol", &targets, &device_index)) return nullptr;
+    PyObject *fast = PySequence_Fast(targets, "targets must be a sequence");
+    if (!fast) return nullptr;
+    const Py_ssize_t B = PySequence_Fast_GET_SIZE(fast);
+    std::vector<uint64_t> ptrs((size_t)(2 * B));
+    std::vector<uint32_t> versions((size_t)(2 * B));
+    PyObject *sizes = PyList_New(B), *tensors = PyList_New(2 * B);
+    int64_t total = 0, max_t = 0;
+    bool ok = sizes && tensors;
+    for (Py_ssize_t b = 0; ok && b < B; ++b) {
+        PyObject *d = PySequence_Fast_GET_ITEM(fast, b);
+        const at::Tensor *l = dict_tensor(d, g_key_labels), *x = dict_tensor(d, g_key_boxes);
+        if (!l || !x) { ok = false; break; }
+        const int64_t n = x->dim() >= 1 ? x->size(0) : -1;
+        ok = n >= 0 && l->scalar_type() == at::kLong && x->scalar_type() == at::kFloat && l->dim() == 1 &&
+             l->size(0) == n && x->numel() == 4 * n && (x->dim() == 2 || n == 0) && l->is_contiguous() &&
+             x->is_contiguous() &&
+             (device_index < 0 ? (l->device().is_cpu() && x->device().is_cpu())      // -1: host tensors (tests)
+                               : (l->device().is_cuda() && x->device().is_cuda() &&
+                                  l->device().index() == device_index && x->device().index() == device_index)) &&
+             (n == 0 || (reinterpret_cast<uintptr_t>(x->data_ptr()) & 15) == 0);
+        if (!ok) break;
+        ptrs[(size_t)(2 * b)] = reinterpret_cast<uint64_t>(l->data_ptr());
+        ptrs[(size_t)(2 * b + 1)] = reinterpret_cast<uint64_t>(x->data_ptr());
+        versions[(size_t)(2 * b)] = l->_version();
+        versions[(size_t)(2 * b + 1)] = x->_version();
+        PyObject *lo = PyDict_GetItem(d, g_key_labels), *xo = PyDict_GetItem(d, g_key_boxes);
+        Py_INCREF(lo);
+        Py_INCREF(xo);
+        PyList_SET_ITEM(tensors, 2 * b, lo);
+        PyList_SET_ITEM(tensors, 2 * b + 1, xo);
+        PyList_SET_ITEM(sizes, b, PyLong_FromLongLong(n));
+        total += n;
+        max_t = n > max_t ? n : max_t;
+    }
+    Py_DECREF(fast);
+    if (!ok) {
+        Py_XDECREF(sizes);
+        Py_XDECREF(tensors);
+        if (PyErr_Occurred()) return nullptr;
+        Py_RETURN_NONE;
+    }
+    // [offsets (B + 1) | order (B)]: exclusive prefix sums, and the images by falling size (stable): the
+    // assignment kernel's tail is set by the largest problems, they go first
+    std::vector<int32_t> meta((size_t)(2 * B + 1));
+    PyObject *offsets = PyList_New(B + 1);
+    if (!offsets || total > INT32_MAX) {
+        Py_XDECREF(offsets);
+        Py_DECREF(sizes);
+        Py_DECREF(tensors);
+        if (PyErr_Occurred()) return nullptr;
+        Py_RETURN_NONE;
+    }
+    int64_t run = 0;
+    for (Py_ssize_t b = 0; b <= B; ++b) {
+        meta[(size_t)b] = (int32_t)run;
+        PyList_SET_ITEM(offsets, b, PyLong_FromLongLong(run));
+        if (b < B) run += PyLong_AsLongLong(PyList_GET_ITEM(sizes, b));
+    }
+    std::vector<int32_t> order((size_t)B);
+    for (Py_ssize_t b = 0; b < B; ++b) order[(size_t)b] = (int32_t)b;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t c) {
+        return meta[(size_t)a + 1] - meta[(size_t)a] > meta[(size_t)c + 1] - meta[(size_t)c];
+    });
+    for (Py_ssize_t b = 0; b < B; ++b) meta[(size_t)(B + 1 + b)] = order[(size_t)b];
+    PyObject *pb = PyBytes_FromStringAndSize(reinterpret_cast<const char *>(ptrs.data()), (Py_ssize_t)(ptrs.size() * 8));
+    PyObject *vb = PyBytes_FromStringAndSize(reinterpret_cast<const char *>(versions.data()), (Py_ssize_t)(versions.size() * 4));
+    PyObject *mb = PyBytes_FromStringAndSize(reinterpret_cast<const char *>(meta.data()), (Py_ssize_t)(meta.size() * 4));
+    return Py_BuildValue("(NLLNNNNN)", sizes, (long long)total, (long long)max_t, pb, tensors, vb, offsets, mb);
+}
+
+// same_targets(targets, tensors, versions) -> bool: `targets` are the very tensor objects of an earlier
+// scan_targets, with unchanged version counters.
+PyObject *same_targets(PyObject *, PyObject *args)
+{
+    PyObject *targets, *tensors, *versions;
+    if (!PyArg_ParseTuple(args, "OOS", &targets, &tensors, &versions)) return nullptr;
+    if (!PyList_Check(tensors)) Py_RETURN_FALSE;
+    PyObject *fast = PySequence_Fast(targets, "targets must be a sequence");
+    if (!fast) return nullptr;
+    const Py_ssize_t B = PySequence_Fast_GET_SIZE(fast);
+    bool same = PyList_GET_SIZE(tensors) == 2 * B && PyBytes_GET_SIZE(versions) == 8 * B;
+    const uint32_t *ver = reinterpret_cast<const uint32_t *>(PyBytes_AS_STRING(versions));
+    for (Py_ssize_t b = 0; same && b < B; ++b) {
+        PyObject *d = PySequence_Fast_GET_ITEM(fast, b);
+        if (!PyDict_Check(d)) { same = false; break; }
+        PyObject *lo = PyDict_GetItem(d, g_key_labels), *xo = PyDict_GetItem(d, g_key_boxes);
+        same = lo && xo && lo == PyList_GET_ITEM(tensors, 2 * b) && xo == PyList_GET_ITEM(tensors, 2 * b + 1) &&
+               THPVariable_Check(lo) && THPVariable_Check(xo) &&
+               THPVariable_Unpack(lo)._version() == ver[2 * b] && THPVariable_Unpack(xo)._version() == ver[2 * b + 1];
+    }
+    Py_DECREF(fast);
+    if (same) Py_RETURN_TRUE;
+    Py_RETURN_FALSE;
+}
+
+// The C ABI's descriptor of one output set (include/detr_match.h, DmSet).
+struct SetRecord {
+    const void *logits, *boxes;
+    int64_t cost_off, out_off;
+    int32_t Q, q_stride;
+};
+static_assert(sizeof(SetRecord) == 40, "must match DmSet");
+
+// scan_outputs(outputs_list, batch, num_targets) -> None, or
+//   (device_index, C, queries: list[int], descriptors: bytes (S DmSet records), cost_floats: int)
+// None unless every set has float32 contiguous pred_logits [batch, Q, C] and pred_boxes [batch, Q, 4] (16-byte
+// aligned) on one CUDA device with one C.  Cost regions are laid out one after the other, row stride = Q
+// rounded up to 32; index regions at s * num_targets.
+PyObject *scan_outputs(PyObject *, PyObject *args)
+{
+    PyObject *outputs;
+    long long batch, M;
+    int allow_host = 0;      // tests only: accept host tensors
+    if (!PyArg_ParseTuple(args, "OLL|p", &outputs, &batch, &M, &allow_host)) return nullptr;
+    PyObject *fast = PySequence_Fast(outputs, "outputs must be a sequence");
+    if (!fast) return nullptr;
+    const Py_ssize_t S = PySequence_Fast_GET_SIZE(fast);
+    std::vector<SetRecord> recs((size_t)S);
+    PyObject *queries = PyList_New(S);
+    bool ok = queries != nullptr && S > 0;
+    int64_t cost_off = 0, C = 0;
+    int device_index = -1;
+    for (Py_ssize_t s = 0; ok && s < S; ++s) {
+        PyObject *d = PySequence_Fast_GET_ITEM(fast, s);
+        const at::Tensor *l = dict_tensor(d, g_key_logits), *x = dict_tensor(d, g_key_pboxes);
+        if (!l || !x) { ok = false; break; }
+        ok = l->dim() == 3 && x->dim() == 3 && l->scalar_type() == at::kFloat && x->scalar_type() == at::kFloat &&
+             l->size(0) == batch && x->size(0) == batch && l->size(1) == x->size(1) && x->size(2) == 4 &&
+             l->size(1) >= 1 && l->size(1) <= INT32_MAX - 32 && l->size(2) >= 1 && l->is_contiguous() &&
+             x->is_contiguous() && (l->device().is_cuda() || allow_host) && x->device() == l->device() &&
+             (reinterpret_cast<uintptr_t>(x->data_ptr()) & 15) == 0;
+        if (!ok) break;
+        if (s == 0) { C = l->size(2); device_index = l->device().index(); }
+        ok = l->size(2) == C && l->device().index() == device_index;
+        if (!ok) break;
+        const int64_t Q = l->size(1), stride = (Q + 31) / 32 * 32;
+        recs[(size_t)s] = SetRecord{l->data_ptr(), x->data_ptr(), cost_off, (int64_t)s * M, (int32_t)Q, (int32_t)stride};
+        cost_off += M * stride;
+        PyList_SET_ITEM(queries, s, PyLong_FromLongLong(Q));
+    }
+    Py_DECREF(fast);
+    if (!ok) {
+        Py_XDECREF(queries);
+        if (PyErr_Occurred()) return nullptr;
+        Py_RETURN_NONE;
+    }
+    PyObject *rb = PyBytes_FromStringAndSize(reinterpret_cast<const char *>(recs.data()), (Py_ssize_t)(recs.size() * sizeof(SetRecord)));
+    return Py_BuildValue("(iLNNL)", device_index, (long long)C, queries, rb, (long long)cost_off);
+}
+
 PyMethodDef methods[] = {
+    {"scan_targets", scan_targets, METH_VARARGS, "metadata and data pointers of a list of target dicts"},
+    {"same_targets", same_targets, METH_VARARGS, "are these the unchanged tensors of an earlier scan_targets"},
+    {"scan_outputs", scan_outputs, METH_VARARGS, "checked DmSet descriptors of a list of output dicts"},
     {"index_pairs", index_pairs, METH_VARARGS, "flat index buffer -> per set, per image (src, tgt) views"},
     {"pool_size", pool_size, METH_NOARGS, "tensor objects kept for recycling"},
     {"clear_pool", clear_pool, METH_NOARGS, "drop the recycled tensor objects"},
@@ -167,4 +352,11 @@ PyModuleDef module = {PyModuleDef_HEAD_INIT, "_index_views", "bulk creation of i
 
 }  // namespace
 
-PyMODINIT_FUNC PyInit__index_views(void) { return PyModule_Create(&module); }
+PyMODINIT_FUNC PyInit__index_views(void)
+{
+    g_key_labels = PyUnicode_InternFromString("labels");
+    g_key_boxes = PyUnicode_InternFromString("boxes");
+    g_key_logits = PyUnicode_InternFromString("pred_logits");
+    g_key_pboxes = PyUnicode_InternFromString("pred_boxes");
+    return PyModule_Create(&module);
+}

@@ -41,6 +41,14 @@ class PackedTargets:
     """
 
     def __init__(self, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device):
+        self.device = device
+        self._source = self._scanned = None
+        if _index_views is not None and device.type == "cuda":
+            index = device.index if device.index is not None else torch.cuda.current_device()
+            scan = _index_views.scan_targets(targets, index)
+            if scan is not None:          # the usual case: int64 labels, float32 [T, 4] boxes, contiguous, on `device`
+                self._pack_scanned(scan, device, index)
+                return
         sizes, label_list, box_list = [], [], []
         for t in targets:                       # one pass over the dicts
             b = t["boxes"]
@@ -54,7 +62,6 @@ class PackedTargets:
         self.batch = B = len(sizes)
         self.total = sum(sizes)
         self.max_t = max(sizes) if sizes else 0
-        self.device = device
         if self.total > 0:
             labels = torch.cat(label_list)
             boxes = torch.cat(box_list)
@@ -79,8 +86,36 @@ class PackedTargets:
         staged = torch.tensor(offsets + order, dtype=torch.int32, pin_memory=True)
         self.meta = staged.to(device, non_blocking=True)
 
+    def _pack_scanned(self, scan, device, index):
+        """Packing through the library's pack kernel (dm_pack_targets): one launch reads every image's tensors
+        through the pointers the scan collected; offsets and order travel as kernel arguments (no upload)."""
+        self.sizes, self.total, self.max_t, pointers, tensors, versions, self.offsets_list, meta = scan
+        self._scanned = (tensors, versions)       # keeps the tensors (and so the pointers) alive
+        self.batch = B = len(self.sizes)
+        M = max(self.total, 1)
+        # one device buffer [boxes f32 4M | labels int64 M | meta int32 2B+1], every part aligned for its type
+        off_labels = 16 * M
+        off_meta = off_labels + 8 * M
+        buf = torch.empty(off_meta + 4 * (2 * B + 1), dtype=torch.uint8, device=device)
+        self.boxes = buf[:off_labels].view(torch.float32).view(M, 4)
+        self.labels = buf[off_labels:off_meta].view(torch.int64)
+        self.meta = buf[off_meta:].view(torch.int32)
+        if self.total == 0:
+            buf[:off_meta].zero_()
+        base = buf.data_ptr()
+        stream = torch.cuda.current_stream(device).cuda_stream
+        if index == torch.cuda.current_device():
+            rc = lib.dm_pack_targets(pointers, meta, B, base + off_labels, base, base + off_meta, stream)
+        else:
+            with torch.cuda.device(device):
+                rc = lib.dm_pack_targets(pointers, meta, B, base + off_labels, base, base + off_meta, stream)
+        _lib.check(rc, "dm_pack_targets")
+
     def same_targets(self, targets) -> bool:
         """True when `targets` are the very tensors this object was packed from, unchanged since."""
+        scanned = getattr(self, "_scanned", None)
+        if scanned is not None:
+            return _index_views.same_targets(targets, scanned[0], scanned[1])
         src = getattr(self, "_source", None)
         if src is None or len(targets) != self.batch:
             return False
@@ -365,10 +400,17 @@ class HungarianMatcher(torch.nn.Module):
             cost = ops.cost(*common) if want_cost else None
             self.last_status = out[2 * S * M:2 * S * M + 1]
             return out, queries, cost, ops.set_array(None, queries, M)[2]
-        device, C, keep, queries = self._prepare_sets(outputs_list, batch)
+        scan = _index_views.scan_outputs(outputs_list, batch, M) if _index_views is not None else None
+        if scan is not None:      # the usual case: float32, contiguous, one device, one class count
+            index, C, queries, sets, cost_off = scan
+            device = outputs_list[0]["pred_logits"].device
+            keep = None
+        else:
+            device, C, keep, queries = self._prepare_sets(outputs_list, batch)
+            sets, cost_off, _ = ops.set_array(keep, queries, M)
         if packed.device != device:
             raise ValueError("targets and predictions must be on the same device")
-        sets, cost_off, strides = ops.set_array(keep, queries, M)
+        strides = ops.set_array(None, queries, M)[2] if want_cost else None
 
         SM = S * M
         if own_buffers:

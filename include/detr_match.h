@@ -85,6 +85,19 @@ const char *dm_last_hip_error(void);
 int dm_device_count(void);
 
 /*
+ * Packs the per-image targets of a batch: replaces the two torch.cat calls of matcher.py:65-66 and
+ * produces tgt_off / order as well, in one launch per 96 images and without any upload (pointers,
+ * offsets and order travel as kernel arguments).
+ *   pointers  host uint64[2 * B]: per image the device address of its int64 labels [T_b] and of its float32
+ *             cxcywh boxes [T_b][4] (16-byte aligned), both contiguous
+ *   meta      host int32[2 * B + 1]: tgt_off (B + 1 exclusive prefix sums of T_b), then the processing order (B)
+ *   labels_out device int64[M], boxes_out device float[M][4] (16-byte aligned), meta_out device int32[2 * B + 1]
+ *             (tgt_off = meta_out, order = meta_out + B + 1)
+ */
+int dm_pack_targets(const uint64_t *pointers, const int32_t *meta, int B, int64_t *labels_out,
+                    float *boxes_out, int32_t *meta_out, void *stream);
+
+/*
  * Fused matching-cost kernel: replaces matcher.py:59-90 and box_ops.py:17-69 for the
  * B diagonal blocks the reference consumes (class cost + L1 + GIoU, weighted sum).
  *   sets     host, S entries            tgt_labels device int64[M]

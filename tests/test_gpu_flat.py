@@ -115,3 +115,41 @@ def test_packed_targets_from_host_empty_batch_member():
     assert p.sizes == [0, 2] and p.offsets_host.tolist() == [0, 0, 2]
     none = detr_amd.PackedTargets.from_host([tg[0], tg[0]], dev)
     assert none.total == 0 and none.max_t == 0
+
+
+def test_pack_kernel_equals_the_torch_packing():
+    """The usual inputs are packed by dm_pack_targets (one launch, pointers as kernel arguments); unusual ones by
+    torch.cat and an upload.  Same labels, boxes, offsets and order either way -- also with empty images and with
+    more images than one launch takes."""
+    import detr_amd
+    import detr_amd.matcher as mm
+    from detr_amd import synth
+
+    device = torch.device("cuda", torch.cuda.current_device())
+    for name, batch in (("cfg2", 7), ("cfg4", 256), ("cfg1", 1)):
+        _, _, targets = synth.make_workload(name, device="cuda", batch=batch)
+        if batch == 7:
+            targets[3] = {"labels": targets[3]["labels"][:0], "boxes": targets[3]["boxes"][:0]}
+        fast = detr_amd.PackedTargets(targets, device)
+        assert fast._scanned is not None
+        helper, mm._index_views = mm._index_views, None
+        try:
+            slow = detr_amd.PackedTargets(targets, device)
+        finally:
+            mm._index_views = helper
+        assert slow._scanned is None and fast.sizes == slow.sizes and fast.total == slow.total
+        assert fast.max_t == slow.max_t and fast.offsets_list == slow.offsets_list
+        assert torch.equal(fast.labels[:fast.total], slow.labels[:slow.total])
+        assert torch.equal(fast.boxes[:fast.total], slow.boxes[:slow.total])
+        assert torch.equal(fast.meta, slow.meta)
+        assert fast.same_targets(targets) and slow.same_targets(targets)
+        assert not fast.same_targets(targets[:-1] + [dict(labels=targets[-1]["labels"].clone(), boxes=targets[-1]["boxes"])])
+    # all images empty; int32 labels and float64 boxes take the general path (and its exceptions)
+    empty = [{"labels": torch.zeros(0, dtype=torch.int64, device="cuda"), "boxes": torch.zeros(0, 4, device="cuda")}] * 3
+    p = detr_amd.PackedTargets(empty, device)
+    assert p.total == 0 and p.meta.tolist() == [0, 0, 0, 0, 0, 1, 2]
+    odd = [{"labels": torch.tensor([1, 0], dtype=torch.int32, device="cuda"), "boxes": torch.rand(2, 4, device="cuda")}]
+    p = detr_amd.PackedTargets(odd, device)
+    assert p._scanned is None and p.labels.dtype == torch.int64 and p.labels.tolist() == [1, 0]
+    with pytest.raises(RuntimeError):
+        detr_amd.PackedTargets([{"labels": torch.tensor([1], device="cuda"), "boxes": torch.rand(1, 4, device="cuda").double()}], device)

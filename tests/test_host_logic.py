@@ -237,3 +237,48 @@ def test_index_view_helper_equals_python_split_and_never_touches_live_tensors():
         seen.append({id(t) for r in result for pair in r for t in pair})
         assert result[0][0][0].tolist() == ([0, 1, 2] if k % 2 else [100, 101, 102])
     assert len(seen[5] & seen[3]) >= 6
+
+
+def test_tensor_scans_of_the_host_helper():
+    """detr_amd._index_views.scan_targets / same_targets / scan_outputs read tensor metadata in bulk; anything
+    unusual is reported as None (the Python code then takes its general path)."""
+    from detr_amd.matcher import _index_views as iv
+
+    targets = [{"labels": torch.tensor([1, 0, 1]), "boxes": torch.rand(3, 4)},
+               {"labels": torch.zeros(0, dtype=torch.int64), "boxes": torch.zeros(0, 4)},
+               {"labels": torch.tensor([0] * 5), "boxes": torch.rand(5, 4)}]
+    sizes, total, max_t, pointers, tensors, versions, offsets, meta = iv.scan_targets(targets, -1)   # -1: host tensors
+    assert sizes == [3, 0, 5] and total == 8 and max_t == 5 and offsets == [0, 3, 3, 8]
+    ptr = np.frombuffer(pointers, dtype=np.uint64)
+    assert ptr[0] == targets[0]["labels"].data_ptr() and ptr[5] == targets[2]["boxes"].data_ptr()
+    assert tensors[0] is targets[0]["labels"] and tensors[5] is targets[2]["boxes"]
+    assert np.frombuffer(meta, dtype=np.int32).tolist() == [0, 3, 3, 8, 2, 0, 1]      # offsets | largest first
+    assert iv.same_targets(targets, tensors, versions)
+    assert iv.same_targets([dict(t) for t in targets], tensors, versions)            # same tensors in new dicts
+    targets[2]["boxes"][0, 0] = 0.5                                                    # in-place change
+    assert not iv.same_targets(targets, tensors, versions)
+    assert not iv.same_targets(targets[:2], tensors, versions)
+    other = [dict(t) for t in targets]
+    other[1] = {"labels": targets[1]["labels"].clone(), "boxes": targets[1]["boxes"]}
+    assert not iv.same_targets(other, tensors, versions)
+    # unusual inputs -> None
+    assert iv.scan_targets([{"labels": torch.zeros(2, dtype=torch.int32), "boxes": torch.rand(2, 4)}], -1) is None
+    assert iv.scan_targets([{"labels": torch.zeros(2, dtype=torch.int64), "boxes": torch.rand(3, 4)}], -1) is None
+    assert iv.scan_targets([{"labels": torch.zeros(2, dtype=torch.int64), "boxes": torch.rand(4, 2).t()}], -1) is None
+    assert iv.scan_targets([{"labels": torch.zeros(2, dtype=torch.int64)}], -1) is None
+    assert iv.scan_targets(targets, 0) is None                                         # not on cuda:0
+
+    outs = [{"pred_logits": torch.rand(3, 10, 2), "pred_boxes": torch.rand(3, 10, 4)},
+            {"pred_logits": torch.rand(3, 70, 2), "pred_boxes": torch.rand(3, 70, 4)}]
+    assert iv.scan_outputs(outs, 3, 8) is None                                         # host tensors need the test flag
+    index, C, queries, recs, cost_floats = iv.scan_outputs(outs, 3, 8, True)
+    assert C == 2 and queries == [10, 70] and cost_floats == 8 * 32 + 8 * 96
+    from detr_amd._lib import DmSet
+    sets = (DmSet * 2).from_buffer_copy(recs)
+    assert sets[0].logits == outs[0]["pred_logits"].data_ptr() and sets[1].boxes == outs[1]["pred_boxes"].data_ptr()
+    assert (sets[0].Q, sets[0].q_stride, sets[0].cost_off, sets[0].out_off) == (10, 32, 0, 0)
+    assert (sets[1].Q, sets[1].q_stride, sets[1].cost_off, sets[1].out_off) == (70, 96, 256, 8)
+    assert iv.scan_outputs(outs, 4, 8, True) is None                                   # batch size mismatch
+    assert iv.scan_outputs([{"pred_logits": torch.rand(3, 10, 2).double(), "pred_boxes": torch.rand(3, 10, 4)}], 3, 8, True) is None
+    assert iv.scan_outputs([outs[0], {"pred_logits": torch.rand(3, 10, 3), "pred_boxes": torch.rand(3, 10, 4)}], 3, 8, True) is None
+    assert iv.scan_outputs([{"pred_logits": torch.rand(3, 10, 2), "pred_boxes": torch.rand(3, 4, 10).transpose(1, 2)}], 3, 8, True) is None

@@ -22,6 +22,8 @@ S = len(sets)
 for it in range(N + 20):
     t0 = time.perf_counter()
     packed = PackedTargets(targets, dev)
+    if os.environ.get("SYNC_AFTER_PACK"):
+        torch.cuda.current_stream(dev).synchronize()
     t1 = time.perf_counter()
     out, queries, cost, strides = m._launch(sets, packed, own_buffers=True)
     t2 = time.perf_counter()
@@ -53,12 +55,13 @@ print(f"{'total':12s} {acc.sum() / N * 1e6:8.1f} us")
 # the same step through the public call, with new target dicts every step (as a training loop has)
 import gc
 gc.disable()
-for label, fresh in (("match_many, new targets list per step", True), ("match_many, same targets object", False)):
+pool = [[{k: v[:] for k, v in t.items()} for t in targets] for _ in range(4)]
+for label, fresh in (("match_many, new target tensors every step", True), ("match_many, same target tensors", False)):
     for _ in range(20):
-        m.match_many(sets, list(targets) if fresh else targets)
+        m.match_many(sets, targets)
     torch.cuda.synchronize()
     t = time.perf_counter()
-    for _ in range(N):
-        m.match_many(sets, [dict(d) for d in targets] if fresh else targets)
+    for k in range(N):
+        m.match_many(sets, pool[k & 3] if fresh else targets)
     torch.cuda.synchronize()
     print(f"{label}: {(time.perf_counter() - t) / N * 1e6:.1f} us")
