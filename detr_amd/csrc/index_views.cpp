@@ -46,7 +46,8 @@ PyObject *view_at(std::vector<PyObject *> &g_pool, size_t slot, const c10::Stora
         PyObject **weak = Py_TYPE(obj)->tp_weaklistoffset ? PyObject_GET_WEAKREFS_LISTPTR(obj) : nullptr;
         if (Py_REFCNT(obj) == 1 && (!weak || !*weak)) {
             const at::Tensor &t = THPVariable_Unpack(obj);
-            if (t.use_count() == 1 && t.weak_use_count() == 1) {
+            // (an object is only re-pointed at storage of the kind it was made for: its dispatch keys stay)
+            if (t.use_count() == 1 && t.weak_use_count() == 1 && t.key_set() == keys) {
                 c10::TensorImpl *impl = t.unsafeGetTensorImpl();
                 impl->set_storage_keep_dtype(storage);
                 impl->set_storage_offset(offset);
@@ -87,7 +88,7 @@ bool read_ints(PyObject *seq, std::vector<int64_t> &out, const char *what)
 }
 
 // index_pairs(flat, M, sizes, queries, offsets) -> list (sets) of lists (images) of (src, tgt)
-//   flat     1-D contiguous int64 CPU tensor of at least 2 * S * M elements
+//   flat     1-D contiguous int64 tensor (host or device) of at least 2 * S * M elements
 //   sizes    targets per image (B ints); offsets: their exclusive prefix sums (B ints are read)
 //   queries  queries per output set (S ints)
 PyObject *index_pairs(PyObject *, PyObject *args)
@@ -107,8 +108,8 @@ PyObject *index_pairs(PyObject *, PyObject *args)
         return nullptr;
     const int64_t S = (int64_t)queries.size(), B = (int64_t)sizes.size();
     if (!flat.defined() || flat.dim() != 1 || flat.scalar_type() != at::kLong || !flat.is_contiguous() ||
-        !flat.device().is_cpu() || M < 0 || flat.numel() < 2 * S * M || (int64_t)offsets.size() < B) {
-        PyErr_SetString(PyExc_ValueError, "index_pairs: flat must be a contiguous 1-D int64 CPU tensor of >= 2*S*M elements");
+        flat.requires_grad() || M < 0 || flat.numel() < 2 * S * M || (int64_t)offsets.size() < B) {
+        PyErr_SetString(PyExc_ValueError, "index_pairs: flat must be a contiguous 1-D int64 tensor of >= 2*S*M elements");
         return nullptr;
     }
     for (int64_t b = 0; b < B; ++b)

@@ -501,7 +501,7 @@ class HungarianMatcher(torch.nn.Module):
         if M == 0:
             empty = flat[:0]
             return [[(empty, empty) for _ in sizes] for _ in range(S)]
-        if _index_views is not None and flat.device.type == "cpu" and flat.dtype == torch.int64:
+        if _index_views is not None and flat.dtype == torch.int64:
             return _index_views.index_pairs(flat, M, sizes, queries, offsets)
         src_all, tgt_all = flat[:S * M], flat[S * M:2 * S * M]
         B = len(sizes)

@@ -395,3 +395,21 @@ def test_tensors_on_a_device_that_is_not_current():
     for s in range(len(sets)):
         for (a0, a1), (b0, b1) in zip(here[s], there[s]):
             assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+def test_device_and_host_index_tuples_alternate():
+    """The bulk view helper recycles tensor objects only for storage of the kind they were made for: calls that
+    return device tuples and calls that return CPU tuples can alternate."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg2", device="cuda", batch=4)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    want = [[(a.clone(), b.clone()) for a, b in per_set] for per_set in matcher.match_many(sets, targets)]
+    for k in range(6):
+        got = matcher.match_many(sets, targets, device_indices=bool(k % 2))
+        for s in range(len(sets)):
+            for (a0, a1), (b0, b1) in zip(want[s], got[s]):
+                assert b0.device.type == ("cuda" if k % 2 else "cpu")
+                assert torch.equal(a0, b0.cpu()) and torch.equal(a1, b1.cpu())
+        del got
