@@ -153,3 +153,30 @@ def test_pack_kernel_equals_the_torch_packing():
     assert p._scanned is None and p.labels.dtype == torch.int64 and p.labels.tolist() == [1, 0]
     with pytest.raises(RuntimeError):
         detr_amd.PackedTargets([{"labels": torch.tensor([1], device="cuda"), "boxes": torch.rand(1, 4, device="cuda").double()}], device)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_io.case_names() if golden_io.load(n).error is None])
+def test_match_flat_against_the_reference_golden_indices(name):
+    """The flat view checked against the REFERENCE's own indices (golden vectors), not against the product's
+    tuples: what the criterion builds from the golden (src, tgt) lists must be what match_flat hands over
+    (identical pairs, or -- where the optimum is not unique -- pairs of equal total cost on the golden cost)."""
+    import detr_amd
+
+    g = golden_io.load(name)
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    flat = matcher.match_flat([outputs], targets)[0]
+    matcher.check_status()
+    golden = [(torch.from_numpy(np.asarray(i)), torch.from_numpy(np.asarray(j))) for i, j in g.indices]
+    bi, si, boxes, labels, dense = _criterion_view(golden, targets, g.B, g.Q, g.C - 1)
+    fb, fs, ft = flat.batch_idx.cpu(), flat.src_idx.cpu(), flat.tgt_idx.cpu()
+    assert fb.shape == bi.shape and torch.equal(fb, bi)
+    if torch.equal(fs, si):
+        assert torch.equal(flat.target_boxes().cpu(), boxes) and torch.equal(flat.target_labels().cpu(), labels)
+        assert torch.equal(flat.target_classes(g.C - 1).cpu(), dense)
+    else:
+        for b in range(g.B):
+            mine = fb == b
+            a = golden_io.assignment_cost(g.cost[b], fs[mine].numpy(), ft[mine].numpy())
+            r = golden_io.assignment_cost(g.cost[b], np.asarray(g.indices[b][0]), np.asarray(g.indices[b][1]))
+            assert abs(a - r) <= 1e-5 * max(1.0, abs(r))
