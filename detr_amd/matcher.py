@@ -97,12 +97,13 @@ class PackedTargets:
         off_labels = 16 * M
         off_meta = off_labels + 8 * M
         buf = torch.empty(off_meta + 4 * (2 * B + 1), dtype=torch.uint8, device=device)
-        self.boxes = buf[:off_labels].view(torch.float32).view(M, 4)
-        self.labels = buf[off_labels:off_meta].view(torch.int64)
-        self.meta = buf[off_meta:].view(torch.int32)
+        # (the tensors `labels`, `boxes`, `meta` are views of this buffer, made when somebody asks for them:
+        # the matcher itself only needs the addresses)
+        self._buf, self._layout = buf, (M, off_labels, off_meta)
         if self.total == 0:
             buf[:off_meta].zero_()
         base = buf.data_ptr()
+        self._pointers = (base + off_labels, base, base + off_meta, base + off_meta + 4 * (B + 1))
         stream = torch.cuda.current_stream(device).cuda_stream
         if index == torch.cuda.current_device():
             rc = lib.dm_pack_targets(pointers, meta, B, base + off_labels, base, base + off_meta, stream)
@@ -110,6 +111,25 @@ class PackedTargets:
             with torch.cuda.device(device):
                 rc = lib.dm_pack_targets(pointers, meta, B, base + off_labels, base, base + off_meta, stream)
         _lib.check(rc, "dm_pack_targets")
+
+    def __getattr__(self, name):
+        # only reached for attributes that are not set: the lazily made views of the pack kernel's buffer
+        if name in ("labels", "boxes", "meta") and "_buf" in self.__dict__:
+            M, off_labels, off_meta = self._layout
+            buf = self._buf
+            self.boxes = buf[:off_labels].view(torch.float32).view(M, 4)
+            self.labels = buf[off_labels:off_meta].view(torch.int64)
+            self.meta = buf[off_meta:].view(torch.int32)
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def device_pointers(self):
+        """Addresses of (labels, boxes, offsets, order) on the device."""
+        ptrs = self.__dict__.get("_pointers")
+        if ptrs is None:
+            meta = self.meta.data_ptr()
+            ptrs = self._pointers = (self.labels.data_ptr(), self.boxes.data_ptr(), meta, meta + 4 * (self.batch + 1))
+        return ptrs
 
     def same_targets(self, targets) -> bool:
         """True when `targets` are the very tensors this object was packed from, unchanged since."""
@@ -430,15 +450,14 @@ class HungarianMatcher(torch.nn.Module):
             self.last_status = out[2 * SM:2 * SM + 1]
         stream = torch.cuda.current_stream(device).cuda_stream
         entry = lib.dm_match_flat_f32 if want_cost else lib.dm_match_fused_f32
+        labels_ptr, boxes_ptr, offsets_ptr, order_ptr = packed.device_pointers()
         if device.index is None or device.index == torch.cuda.current_device():
-            rc = entry(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
-                                       packed.offsets_ptr, packed.order_ptr, packed.max_t, self._params_ref(),
-                                       cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
+            rc = entry(sets, S, batch, C, labels_ptr, boxes_ptr, offsets_ptr, order_ptr, packed.max_t,
+                       self._params_ref(), cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
         else:
             with torch.cuda.device(device):
-                rc = entry(sets, S, batch, C, packed.labels.data_ptr(), packed.boxes.data_ptr(),
-                                           packed.offsets_ptr, packed.order_ptr, packed.max_t, self._params_ref(),
-                                           cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
+                rc = entry(sets, S, batch, C, labels_ptr, boxes_ptr, offsets_ptr, order_ptr, packed.max_t,
+                           self._params_ref(), cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
         _lib.check(rc, "dm_match_flat_f32" if want_cost else "dm_match_fused_f32")
         return out, queries, cost, strides
 
