@@ -41,7 +41,7 @@ class DmParams(ctypes.Structure):
 
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_pack_targets", "dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
-           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_noalloc_f32",
+           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_targets_f32", "dm_match_noalloc_f32",
            "dm_profile_enable", "dm_profile_read",
            "dm_debug_set_knob",
            "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
@@ -79,6 +79,9 @@ def _load():
     lib.dm_match_flat_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, prmp, vp, i64p, i64p, i64p, vp, vp]
     lib.dm_match_fused_f32.restype = ctypes.c_int
     lib.dm_match_fused_f32.argtypes = lib.dm_match_flat_f32.argtypes
+    lib.dm_match_targets_f32.restype = ctypes.c_int
+    lib.dm_match_targets_f32.argtypes = [setp, i32, i32, i32, ctypes.c_char_p, ctypes.c_char_p, i32, prmp, vp, vp, vp, vp,
+                                         i64p, i64p, i64p, vp, vp, ctypes.POINTER(ctypes.c_int)]
     lib.dm_match_noalloc_f32.restype = ctypes.c_int
     lib.dm_match_noalloc_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, i32, prmp, i64p, i64p, vp, vp]
     isetp = ctypes.POINTER(DmIndexSet)
@@ -110,7 +113,7 @@ lib = _load()
 
 
 #: launch-shape knobs of dm_debug_set_knob (testing / tuning aid; 0 = automatic)
-KNOBS = {"lap_kernel": 0, "lap_max_waves": 1, "cost_qpt": 2, "cost_tsplit": 3, "tile_waves": 4, "lap_lds_kb": 5, "lap_wave_budget": 6, "no_fuse": 7}
+KNOBS = {"lap_kernel": 0, "lap_max_waves": 1, "cost_qpt": 2, "cost_tsplit": 3, "tile_waves": 4, "lap_lds_kb": 5, "lap_wave_budget": 6, "no_fuse": 7, "no_direct": 8}
 
 
 def set_knob(name: str, value: int):

@@ -22,6 +22,7 @@ int set_lap_knob(int knob, int value);
 }  // namespace dm
 
 namespace {
+int g_no_direct = 0;     // DM_KNOB_DIRECT_TARGETS: 1 = dm_match_targets_f32 always packs the targets first (testing aid)
 int g_no_fuse = 0;      // DM_KNOB_FUSE: 1 = dm_match_fused_f32 always takes the two-kernel path (testing aid)
 }
 
@@ -38,6 +39,10 @@ extern "C" int dm_debug_set_knob(int knob, int value)
     case DM_KNOB_FUSE:
         if (value < 0 || value > 1) return DM_E_INVALID_ARG;
         g_no_fuse = value;
+        return DM_OK;
+    case DM_KNOB_DIRECT_TARGETS:
+        if (value < 0 || value > 1) return DM_E_INVALID_ARG;
+        g_no_direct = value;
         return DM_OK;
     }
     return DM_E_INVALID_ARG;
@@ -132,6 +137,60 @@ extern "C" int dm_match_fused_f32(const DmSet *sets, int S, int B, int C, const 
         rc = dm::lap_run(sets, S, B, workspace, tgt_off, order, max_T, src_out, tgt_out, flat_out, status, st, &fin,
                          workspace);
     }
+    if (g_profile) { (void)hipEventRecord(g_ev[2], st); g_ev_valid = rc == DM_OK; }
+    return rc;
+}
+
+// dm_pack_targets + dm_match_fused_f32 in one call -- and, when the step runs as one fused kernel and the batch
+// fits the kernel-argument table, without the packing: the kernel reads every image's targets through the
+// pointers it is handed.
+extern "C" int dm_pack_targets(const uint64_t *pointers, const int32_t *meta, int B, int64_t *labels_out,
+                               float *boxes_out, int32_t *meta_out, void *stream);
+
+extern "C" int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, const uint64_t *pointers,
+                                    const int32_t *meta, int max_T, const DmParams *params, int64_t *labels_buf,
+                                    float *boxes_buf, int32_t *meta_buf, float *workspace, int64_t *src_out,
+                                    int64_t *tgt_out, int64_t *flat_out, int32_t *status, void *stream, int *packed)
+{
+    if (S < 0 || B < 0 || C < 1 || max_T < 0 || !params || !status || !packed) return DM_E_INVALID_ARG;
+    *packed = 0;
+    if (S == 0 || B == 0) return DM_OK;
+    if (!sets || !pointers || !meta || !labels_buf || !boxes_buf || !meta_buf || !workspace || !src_out || !tgt_out)
+        return DM_E_INVALID_ARG;
+    bool direct = !g_no_fuse && !g_no_direct && B <= dm::DIRECT_MAX_IMAGES && max_T > 0 && dm::lap_can_fuse(C, max_T) && S <= 4096;
+    if (direct) {
+        for (int s = 0; s < S; ++s)
+            if (!sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
+        unsigned char needs_cost[4096];
+        int rc = dm::lap_plan(sets, S, B, max_T, needs_cost);
+        if (rc != DM_OK) return rc;
+        for (int s = 0; s < S; ++s) direct = direct && !needs_cost[s];      // every set in a fused launch
+    }
+    if (!direct) {
+        int rc = dm_pack_targets(pointers, meta, B, labels_buf, boxes_buf, meta_buf, stream);
+        if (rc != DM_OK) return rc;
+        *packed = 1;
+        return dm_match_fused_f32(sets, S, B, C, labels_buf, boxes_buf, meta_buf, meta_buf + B + 1, max_T, params,
+                                  workspace, src_out, tgt_out, flat_out, status, stream);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dm::FusedIn fin;
+    fin.labels = nullptr;
+    fin.tboxes = nullptr;
+    fin.prm = *params;
+    fin.C = C;
+    fin.direct = 1;
+    for (int b = 0; b < B; ++b) {
+        fin.table.labels[b] = reinterpret_cast<const int64_t *>(pointers[2 * (size_t)b]);
+        fin.table.boxes[b] = reinterpret_cast<const float *>(pointers[2 * (size_t)b + 1]);
+        fin.table.offsets[b] = meta[b];
+        fin.table.order[b] = meta[B + 1 + b];
+    }
+    fin.table.offsets[B] = meta[B];
+    if (g_profile) { (void)hipEventRecord(g_ev[0], st); (void)hipEventRecord(g_ev[1], st); }
+    // (tgt_off / order are not read by a launch that has the table: every set of this call is in one)
+    int rc = dm::lap_run(sets, S, B, workspace, meta_buf, meta_buf + B + 1, max_T, src_out, tgt_out, flat_out, status, st,
+                         &fin, workspace);
     if (g_profile) { (void)hipEventRecord(g_ev[2], st); g_ev_valid = rc == DM_OK; }
     return rc;
 }

@@ -142,29 +142,41 @@ __device__ __forceinline__ void small_class_costs(const float (&x)[4], const int
 }
 
 // What an assignment kernel that computes its own cost blocks needs besides the output sets.
+// The targets of up to DIRECT_MAX_IMAGES images as the caller holds them -- one labels and one boxes tensor per
+// image -- with the offsets and the processing order, all travelling in the kernel-argument segment: a
+// kernel that takes them needs no packed copy of the targets and no upload.
+constexpr int DIRECT_MAX_IMAGES = 96;
+struct DirectTargets {
+    const int64_t *labels[DIRECT_MAX_IMAGES];
+    const float *boxes[DIRECT_MAX_IMAGES];
+    int32_t offsets[DIRECT_MAX_IMAGES + 1];
+    int32_t order[DIRECT_MAX_IMAGES];
+};
+
 struct FusedIn {
     const int64_t *labels;   // device, packed target labels
     const float *tboxes;     // device, packed target boxes [M][4] cxcywh
     DmParams prm;
     int C;                   // logits per query, 1..4
+    int direct;              // != 0: the targets are read through `table` instead of the packed arrays
+    DirectTargets table;
 };
 
 // The cost block of problem (set, image b) computed by the workgroup that is going to solve it
 // (`nthreads` threads, this one is `tid`; thread `tid` owns the columns (queries) tid + nthreads * k,
 // k < NCOL).  Row i (target t0 + i) goes to lds_rows + i * ls for i < R and to spill + i * qs beyond;
 // every entry is written by the thread that owns its column -- the only thread that reads it later.
-// tg: LDS room for the image's nr target records.  Returns whether this thread met an entry scipy
+// tl, tb: the image's nr labels and boxes.  tg: LDS room for the image's nr target records.  Returns whether this thread met an entry scipy
 // rejects (NaN or -inf); raises the status bits of the cost kernel (label range, degenerate boxes).
 // Ends with a barrier.
 template <int NCOL>
 __device__ __forceinline__ bool compute_cost_block(const DmSet &set, const FusedIn &fin, const int b, const int nc,
-                                                   const int nr, const int t0, const int tid, const int nthreads,
-                                                   TgtRec *tg, float *lds_rows, const int ls, const int R,
-                                                   float *spill, const int qs, int32_t *status)
+                                                   const int nr, const int64_t *tl, const float4 *tb, const int tid,
+                                                   const int nthreads, TgtRec *tg, float *lds_rows, const int ls,
+                                                   const int R, float *spill, const int qs, int32_t *status)
 {
     const int C = fin.C;
-    for (int i = tid; i < nr; i += nthreads)
-        store_target(tg + i, reinterpret_cast<const float4 *>(fin.tboxes)[t0 + i], fin.labels[t0 + i], C, status);
+    for (int i = tid; i < nr; i += nthreads) store_target(tg + i, tb[i], tl[i], C, status);
     __syncthreads();
     bool bad = false;
     // (Requesting the thread's first prediction ahead of the targets, to overlap the two memory latencies,

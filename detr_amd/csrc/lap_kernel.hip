@@ -491,11 +491,26 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     const int QCAP = BS * NCOL;
     const int s = blockIdx.x % S;
     const int bi = blockIdx.x / S;
-    const int b = order ? order[bi] : bi;
     const DmSet &set = sets.s[s];
     const int nc = set.Q;                 // columns = queries
-    const int t0 = tgt_off[b];
-    const int nr = tgt_off[b + 1] - t0;   // rows = targets
+    int b, t0, nr;                        // image, its first packed target, rows = targets
+    const int64_t *tl = nullptr;          // FUSED: the image's labels and boxes
+    const float4 *tb = nullptr;
+    if (FUSED && fin.direct) {
+        b = fin.table.order[bi];
+        t0 = fin.table.offsets[b];
+        nr = fin.table.offsets[b + 1] - t0;
+        tl = fin.table.labels[b];
+        tb = reinterpret_cast<const float4 *>(fin.table.boxes[b]);
+    } else {
+        b = order ? order[bi] : bi;
+        t0 = tgt_off[b];
+        nr = tgt_off[b + 1] - t0;
+        if (FUSED) {
+            tl = fin.labels + t0;
+            tb = reinterpret_cast<const float4 *>(fin.tboxes) + t0;
+        }
+    }
     if (FUSED && nr == 0) {
         // an image without targets: its predictions are still validated (the reference asserts on the whole batch)
         bool okb = true;
@@ -552,7 +567,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     const int nfl = R * ls;
     bool bad = false;
     if (FUSED) {
-        bad = dm::compute_cost_block<NCOL>(set, fin, b, nc, nr, t0, tid, BS, tg, crow, ls, R,
+        bad = dm::compute_cost_block<NCOL>(set, fin, b, nc, nr, tl, tb, tid, BS, tg, crow, ls, R,
                                            cost_w + set.cost_off + (size_t)t0 * qs, qs, status);
     } else if (linear) {
         for (int base = wave * 256; base < nfl; base += W * 256) {

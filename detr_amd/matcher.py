@@ -40,14 +40,16 @@ class PackedTargets:
     offsets and the largest-first processing order travel in one small upload.
     """
 
-    def __init__(self, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device):
+    def __init__(self, targets: Sequence[Dict[str, torch.Tensor]], device: torch.device, defer: bool = False):
+        """defer=True (what the matcher uses for targets it packs itself): the packed arrays are only filled when
+        somebody needs them -- a step that runs as one fused kernel reads the targets where they are."""
         self.device = device
         self._source = self._scanned = None
         if _index_views is not None and device.type == "cuda":
             index = device.index if device.index is not None else torch.cuda.current_device()
             scan = _index_views.scan_targets(targets, index)
             if scan is not None:          # the usual case: int64 labels, float32 [T, 4] boxes, contiguous, on `device`
-                self._pack_scanned(scan, device, index)
+                self._pack_scanned(scan, device, index, defer)
                 return
         sizes, label_list, box_list = [], [], []
         for t in targets:                       # one pass over the dicts
@@ -86,7 +88,7 @@ class PackedTargets:
         staged = torch.tensor(offsets + order, dtype=torch.int32, pin_memory=True)
         self.meta = staged.to(device, non_blocking=True)
 
-    def _pack_scanned(self, scan, device, index):
+    def _pack_scanned(self, scan, device, index, defer=False):
         """Packing through the library's pack kernel (dm_pack_targets): one launch reads every image's tensors
         through the pointers the scan collected; offsets and order travel as kernel arguments (no upload)."""
         self.sizes, self.total, self.max_t, pointers, tensors, versions, self.offsets_list, meta = scan
@@ -100,21 +102,34 @@ class PackedTargets:
         # (the tensors `labels`, `boxes`, `meta` are views of this buffer, made when somebody asks for them:
         # the matcher itself only needs the addresses)
         self._buf, self._layout = buf, (M, off_labels, off_meta)
-        if self.total == 0:
-            buf[:off_meta].zero_()
         base = buf.data_ptr()
         self._pointers = (base + off_labels, base, base + off_meta, base + off_meta + 4 * (B + 1))
-        stream = torch.cuda.current_stream(device).cuda_stream
+        self._unpacked = (pointers, meta, index)      # what dm_pack_targets needs; None once the buffer is filled
+        if not defer:
+            self._ensure_packed()
+
+    def _ensure_packed(self):
+        pending = self.__dict__.get("_unpacked")
+        if pending is None:
+            return
+        pointers, meta, index = pending
+        self._unpacked = None
+        M, off_labels, off_meta = self._layout
+        if self.total == 0:
+            self._buf[:off_meta].zero_()
+        labels_ptr, boxes_ptr, meta_ptr, _ = self._pointers
+        stream = torch.cuda.current_stream(self.device).cuda_stream
         if index == torch.cuda.current_device():
-            rc = lib.dm_pack_targets(pointers, meta, B, base + off_labels, base, base + off_meta, stream)
+            rc = lib.dm_pack_targets(pointers, meta, self.batch, labels_ptr, boxes_ptr, meta_ptr, stream)
         else:
-            with torch.cuda.device(device):
-                rc = lib.dm_pack_targets(pointers, meta, B, base + off_labels, base, base + off_meta, stream)
+            with torch.cuda.device(self.device):
+                rc = lib.dm_pack_targets(pointers, meta, self.batch, labels_ptr, boxes_ptr, meta_ptr, stream)
         _lib.check(rc, "dm_pack_targets")
 
     def __getattr__(self, name):
         # only reached for attributes that are not set: the lazily made views of the pack kernel's buffer
         if name in ("labels", "boxes", "meta") and "_buf" in self.__dict__:
+            self._ensure_packed()
             M, off_labels, off_meta = self._layout
             buf = self._buf
             self.boxes = buf[:off_labels].view(torch.float32).view(M, 4)
@@ -125,6 +140,7 @@ class PackedTargets:
 
     def device_pointers(self):
         """Addresses of (labels, boxes, offsets, order) on the device."""
+        self._ensure_packed()
         ptrs = self.__dict__.get("_pointers")
         if ptrs is None:
             meta = self.meta.data_ptr()
@@ -238,11 +254,11 @@ class PackedTargets:
 
     @property
     def offsets_ptr(self) -> int:
-        return self.meta.data_ptr()
+        return self.device_pointers()[2]
 
     @property
     def order_ptr(self) -> int:
-        return self.meta.data_ptr() + 4 * (self.batch + 1)
+        return self.device_pointers()[3]
 
 
 class FlatMatches:
@@ -317,6 +333,10 @@ class HungarianMatcher(torch.nn.Module):
         # (they are always used while torch.compile traces); False: the same C entry points directly,
         # which saves the operator dispatch and a fresh index buffer per call
         self.through_ops = False
+        # True: the kernels store the indices of a CPU-tuple call straight into the pinned host tensor the
+        # tuples are views of (the stores cross the bus while the kernel runs); False: into a device buffer
+        # that a copy engine transfers afterwards
+        self.indices_to_host = True
         self._events = {}
         self._buffers = {}
         self._packed = None
@@ -336,7 +356,7 @@ class HungarianMatcher(torch.nn.Module):
     def __setstate__(self, state):
         super().__setstate__(state)
         for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None),
-                            ("through_ops", False)):
+                            ("through_ops", False), ("indices_to_host", True)):
             self.__dict__.setdefault(name, value)
 
     def _done_event(self, device) -> torch.cuda.Event:
@@ -380,7 +400,7 @@ class HungarianMatcher(torch.nn.Module):
         if cached is not None and cached.device == device and cached.same_targets(targets):
             return cached
         self._packed = None          # (a failed packing must not leave a stale entry)
-        packed = PackedTargets(targets, device)
+        packed = PackedTargets(targets, device, defer=True)
         self._packed = packed
         return packed
 
@@ -400,12 +420,13 @@ class HungarianMatcher(torch.nn.Module):
         return ws
 
     def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False, own_buffers: bool = False,
-                want_cost: bool = False):
+                want_cost: bool = False, host_out: Optional[torch.Tensor] = None):
         """Enqueue the cost and assignment kernels for all output sets on the current stream.
         Returns the device index buffer, the queries per set, the cost buffer and, per set, (offset, row
         stride) of its cost region.  Index buffer: a fresh [src (S*M) | tgt (S*M) | status word (| flat
         (S*M))] that the caller may keep, or with `own_buffers` this matcher's own [status | src | tgt],
-        valid until its next call.  Unless `want_cost`, the assignment kernels compute their cost blocks
+        valid until its next call -- or `host_out`, a pinned host tensor of that layout whose status word is
+        zero, which the kernels then write through the bus.  Unless `want_cost`, the assignment kernels compute their cost blocks
         themselves where the shapes allow it (dm_match_fused_f32) and the cost buffer is only a workspace."""
         S, batch, M = len(outputs_list), packed.batch, packed.total
         if self.through_ops or torch.compiler.is_compiling():
@@ -434,8 +455,8 @@ class HungarianMatcher(torch.nn.Module):
 
         SM = S * M
         if own_buffers:
-            ws = self._workspace(device, 2 * SM + 1, max(cost_off, 1))
-            out, cost = ws["out"], ws["cost"]
+            ws = self._workspace(device, 0 if host_out is not None else 2 * SM + 1, max(cost_off, 1))
+            out, cost = (host_out if host_out is not None else ws["out"]), ws["cost"]
             status_ptr = out.data_ptr()
             src_ptr = status_ptr + 8
             flat_ptr = None
@@ -450,6 +471,26 @@ class HungarianMatcher(torch.nn.Module):
             self.last_status = out[2 * SM:2 * SM + 1]
         stream = torch.cuda.current_stream(device).cuda_stream
         entry = lib.dm_match_flat_f32 if want_cost else lib.dm_match_fused_f32
+        pending = packed.__dict__.get("_unpacked")
+        if pending is not None and not want_cost:
+            # targets not packed yet: one call that packs and matches -- or, when the step is one fused kernel,
+            # only matches, the kernel reading the targets where they are
+            pointers, meta, _ = pending
+            labels_ptr, boxes_ptr, meta_ptr, _ = packed._pointers
+            did_pack = ctypes.c_int(0)
+            args = (sets, S, batch, C, pointers, meta, packed.max_t, self._params_ref(), labels_ptr, boxes_ptr, meta_ptr,
+                    cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream, ctypes.byref(did_pack))
+            if device.index is None or device.index == torch.cuda.current_device():
+                rc = lib.dm_match_targets_f32(*args)
+            else:
+                with torch.cuda.device(device):
+                    rc = lib.dm_match_targets_f32(*args)
+            _lib.check(rc, "dm_match_targets_f32")
+            if did_pack.value:
+                if packed.total == 0:
+                    packed._buf[:packed._layout[2]].zero_()
+                packed._unpacked = None
+            return out, queries, cost, strides
         labels_ptr, boxes_ptr, offsets_ptr, order_ptr = packed.device_pointers()
         if device.index is None or device.index == torch.cuda.current_device():
             rc = entry(sets, S, batch, C, labels_ptr, boxes_ptr, offsets_ptr, order_ptr, packed.max_t,
@@ -489,10 +530,15 @@ class HungarianMatcher(torch.nn.Module):
             result = self._split(out, S, M, sizes, queries, packed.offsets_list)
         else:
             own = not (return_cost or self.through_ops or torch.compiler.is_compiling())
-            out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=own, want_cost=return_cost)
             n = 2 * S * M + 1
             host = torch.empty(n, dtype=torch.int64, pin_memory=True)
-            host.copy_(out[:n], non_blocking=True)
+            direct = own and self.indices_to_host and device.index in (None, torch.cuda.current_device())
+            if direct:
+                host[0] = 0                  # the status word: the kernels only ever OR bits into it
+                out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=True, host_out=host)
+            else:
+                out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=own, want_cost=return_cost)
+                host.copy_(out[:n], non_blocking=True)
             done = self._done_event(device)
             done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
             # the per-image views depend on shapes only: build them while the GPU is working
@@ -506,7 +552,7 @@ class HungarianMatcher(torch.nn.Module):
                 done.synchronize()
             bits = int(host[status_at]) & 0xFFFFFFFF
             if bits:
-                if own:
+                if own and not direct:
                     out[:1].zero_()          # the kept buffer's status word, for the next call
                 _raise_for_status(bits)
         if return_cost:

@@ -166,6 +166,21 @@ int dm_match_fused_f32(const DmSet *sets, int S, int B, int C,
                        int32_t *status, void *stream);
 
 /*
+ * A whole matcher call from the reference's own inputs: dm_pack_targets followed by dm_match_fused_f32 -- or,
+ * when the step runs as one fused kernel and B <= 96, that kernel alone, reading every image's labels and boxes
+ * through the pointers (they travel, with offsets and order, as kernel arguments): no packed copy, no second launch.
+ *   pointers, meta              as for dm_pack_targets
+ *   labels_buf, boxes_buf, meta_buf   device room for the packed targets (M int64, M x 4 float 16-byte aligned,
+ *                               2 * B + 1 int32); filled only when the call had to pack: *packed says so
+ *   the rest                    as for dm_match_fused_f32
+ * The per-image tensors must stay alive and unchanged until the call's work on `stream` has completed.
+ */
+int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, const uint64_t *pointers, const int32_t *meta,
+                         int max_T, const DmParams *params, int64_t *labels_buf, float *boxes_buf, int32_t *meta_buf,
+                         float *workspace, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out, int32_t *status,
+                         void *stream, int *packed);
+
+/*
  * dm_match_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The cost
  * blocks between the two kernels live in a fixed array of DM_NOALLOC_MAX_COST_FLOATS floats (32 MiB)
@@ -292,6 +307,7 @@ int dm_profile_read(float *cost_ms, float *lap_ms);
 #define DM_KNOB_TILE_WAVES 4     /* 4 / 8: wavefronts per workgroup in the C > 4 cost kernel */
 #define DM_KNOB_LAP_LDS_KB 5     /* 1..80: LDS budget per problem of the register assignment kernels, in KB */
 #define DM_KNOB_LAP_WAVE_BUDGET 6  /* wavefronts one launch of the workgroup-per-problem kernel may ask for */
+#define DM_KNOB_DIRECT_TARGETS 8  /* 1: dm_match_targets_f32 packs the targets whatever the shapes */
 #define DM_KNOB_FUSE 7           /* 1: dm_match_fused_f32 takes the two-kernel path whatever the shapes */
 int dm_debug_set_knob(int knob, int value);
 

@@ -103,3 +103,57 @@ def test_fused_path_reports_the_reference_errors():
         matcher.match_many([nan], targets)
     ok = matcher.match_many([sets[0]], targets)
     assert len(ok[0]) == 4
+
+
+@pytest.mark.parametrize("name,batch", [("cfg1", None), ("cfg2", None), ("cfg3_hw", 16), ("cfg5", 96), ("cfg5", 128)])
+def test_targets_read_in_place_equal_packed_targets(name, batch):
+    """A step that runs as one fused kernel reads every image's labels and boxes through the pointers it is handed
+    (up to 96 images); with more images, or with the knob, the targets are packed first.  Same indices."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    direct = matcher.match_many(sets, targets)
+    was_direct = matcher._packed._unpacked is not None          # the packed arrays were never filled
+    assert was_direct == (len(targets) <= 96)
+    detr_amd._lib.set_knob("no_direct", 1)
+    try:
+        packed_first = matcher.match_many(sets, [dict(t) for t in targets[:-1]] + [
+            {"labels": targets[-1]["labels"].clone(), "boxes": targets[-1]["boxes"]}])      # (defeats the reuse)
+        assert matcher._packed._unpacked is None
+    finally:
+        detr_amd._lib.set_knob("no_direct", 0)
+    _assert_identical(direct, packed_first)
+    # the packed arrays appear when somebody asks for them
+    p = matcher._packed_for(targets, torch.device("cuda", torch.cuda.current_device()))
+    ref = detr_amd.PackedTargets(targets, p.device)
+    assert torch.equal(p.labels, ref.labels) and torch.equal(p.boxes, ref.boxes) and torch.equal(p.meta, ref.meta)
+    flats = matcher.match_flat(sets, targets)
+    for s, f in enumerate(flats):
+        assert torch.equal(f.src_idx.cpu(), torch.cat([i for i, _ in direct[s]]))
+
+
+@pytest.mark.parametrize("name,batch", [("cfg2", 16), ("cfg4", 8), ("cfg5", 8)])
+def test_indices_stored_to_host_memory_equal_copied_indices(name, batch):
+    """The CPU tuples are views of a pinned host tensor that the kernels either write themselves or that a copy
+    fills from a device buffer: same tuples, same exceptions, and a raised status does not leak into the next call."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    assert matcher.indices_to_host
+    direct = matcher.match_many(sets, targets)
+    assert not direct[0][0][0].is_cuda and direct[0][0][0].is_pinned()
+    matcher.indices_to_host = False
+    copied = matcher.match_many(sets, targets)
+    _assert_identical(direct, copied)
+    C = sets[0]["pred_logits"].shape[-1]
+    bad = [dict(t) for t in targets]
+    bad[0] = {"labels": torch.full_like(targets[0]["labels"], C), "boxes": targets[0]["boxes"]}
+    for to_host in (True, False, True):
+        matcher.indices_to_host = to_host
+        with pytest.raises(IndexError):
+            matcher.match_many(sets, bad)
+        _assert_identical(direct, matcher.match_many(sets, targets))
