@@ -164,6 +164,32 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
 // Grid (tile, image, set).  (Giving all tiles of an
 // image to workgroups of one XCD, so that the 256-byte pieces of a cost row meet in one L2, measured
 // 5 % slower: it concentrates the heavy images on single XCDs.)
+// max(a, b) as the single instruction it is (fmaxf adds a canonicalising v_max per operand: the tile kernel issues
+// one of these per logit).  NaN operands: the instruction returns the other operand, like fmaxf.
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Sum (or maximum) over each group of 16 consecutive lanes, returned in all 16: pairs, quads, halves, row --
+// one DPP-operand instruction per step (the s_nop covers the VALU-write -> DPP-read hazard, which the
+// compiler does not track through inline assembly).
+template <bool SUM>
+__device__ __forceinline__ float row16_all(float x)
+{
+#define DM_ROW16_STEP(CTRL)                                                                                     \
+    if (SUM) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(x)); \
+    else asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(x) : "v"(x));
+    DM_ROW16_STEP("quad_perm:[1,0,3,2]")
+    DM_ROW16_STEP("quad_perm:[2,3,0,1]")
+    DM_ROW16_STEP("row_half_mirror")
+    DM_ROW16_STEP("row_mirror")
+#undef DM_ROW16_STEP
+    return x;
+}
+
 // MODE: 0 softmax class cost, 1 focal with gamma == 2, 2 focal with any gamma.
 template <int W, int MODE>
 __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets, const int nsets, const int B,
@@ -175,8 +201,8 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     constexpr int NT = 64 * W;
     extern __shared__ __align__(16) unsigned char smem[];
     TgtRec *tg = reinterpret_cast<TgtRec *>(smem);                                   // [TCHUNK]
-    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [16][64] softmax partials
-    float *tile = part + (MODE == 0 ? 64 * 16 : 0);                                   // [64][C]
+    float *part = reinterpret_cast<float *>(smem + TCHUNK * sizeof(TgtRec));         // [2][64] softmax statistics
+    float *tile = part + (MODE == 0 ? 64 * 2 : 0);                                    // [64][C]
 
     // grid (tiles, images, sets): no integer division in the prologue (each costs ~25 instructions, and
     // this kernel is bound by the instructions it issues); x runs fastest, so the tiles of an image
@@ -252,59 +278,70 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     constexpr float LOG2E = 1.44269504088896f;
     float ce_max = 0.0f, ce_scale = 1.0f;      // class cost -softmax = exp2((x - ce_max) * LOG2E) * ce_scale
     if (MODE == 0) {
-        // Softmax statistics of the lane's row in ONE pass over the tile.  The walk over the row is
-        // k -> column (k + rot) mod C, rot = lane for even C (bank spreading), 0 otherwise.  The walk
-        // positions form 16 residue classes (mod 16); a wavefront runs its 16 / W classes as
-        // independent chains side by side.  A chain keeps a running maximum m and the sum s of
-        // exp(x - m), rescaled when m grows (one exponential per element either way).  Chains c and
-        // c + 8 always sit in the same wavefront and are merged there; the 8 merged pairs meet in LDS
-        // and are merged in a fixed order, so the result does not depend on the number of wavefronts.
-        constexpr int NCH = 16 / W;
-        const int rot = (C & 1) ? 0 : lane % C;     // (C may be smaller than the wavefront)
-        float m[NCH], sum[NCH];
+        // Softmax statistics (row maximum, -1 / sum of exp(x - max): the reference's own formulation) of the 64 rows.
+        // Sixteen lanes share a row and walk its columns side by side (consecutive words: no index arithmetic per
+        // element), four rows per wavefront and group, the groups interleaved; the sixteen partial results meet through four DPP steps in a
+        // fixed order, so the result depends neither on the number of wavefronts nor on which of them took the row.
+        constexpr int NG = 16 / W;                  // row groups per wavefront: rows 4 * wave + 4 * W * g + (lane >> 4)
+        const int sub = lane & 15;
+        const int r = 4 * wave + (lane >> 4);       // rows >= nq read tile space nobody wrote: results unused
+        const float *xrow = tile + r * C + sub;
+        const int gstep = 4 * W * C;
+        float mx[NG], sum[NG];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) { m[i] = -3.0e38f; sum[i] = 0.0f; }   // finite start: a -inf logit adds 0
-        auto take = [&](int i, int k) {
-            int c = k + rot;
-            c = c >= C ? c - C : c;
-            const float x = xr[c];
-            const float d = x - m[i];        // subtract first: exact for nearby logits however large they are
-            const float e = __builtin_amdgcn_exp2f(-fabsf(d) * LOG2E);
-            sum[i] = d > 0.0f ? __builtin_fmaf(sum[i], e, 1.0f) : sum[i] + e;
-            m[i] = fmaxf(m[i], x);
-        };
-        int k0 = 0;
-        for (; k0 + 16 <= C; k0 += 16) {
+        for (int g = 0; g < NG; ++g) { mx[g] = -INFINITY; sum[g] = 0.0f; }
+        const int nfull = C >> 4;                   // chunks of 16 columns that every lane of the group has
+        const bool tail = sub < (C & 15);
+        {
+            const float *p = xrow;
+            int k = nfull;
+            for (; k >= 4; k -= 4, p += 64) {
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) take(i, k0 + wave + W * i);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], p[g * gstep + 16 * j]);
+            }
+            for (; k > 0; --k, p += 16) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], p[g * gstep]);
+            }
+            if (tail) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], p[g * gstep]);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (k0 + wave + W * i < C) take(i, k0 + wave + W * i);
+        for (int g = 0; g < NG; ++g) mx[g] = row16_all<false>(mx[g]);
+        {
+            auto term = [&](int g, float x) { sum[g] += __builtin_amdgcn_exp2f((x - mx[g]) * LOG2E); };
+            const float *p = xrow;
+            int k = nfull;
+            for (; k >= 4; k -= 4, p += 64) {
 #pragma unroll
-        for (int i = 0; i < NCH / 2; ++i) {       // classes wave + W*i and wave + W*i + 8
-            const int j = i + NCH / 2;
-            const float mm = fmaxf(m[i], m[j]);
-            const float s2 = __builtin_fmaf(sum[i], __builtin_amdgcn_exp2f((m[i] - mm) * LOG2E),
-                                            sum[j] * __builtin_amdgcn_exp2f((m[j] - mm) * LOG2E));
-            part[(wave + W * i) * 64 + lane] = mm;
-            part[(8 + wave + W * i) * 64 + lane] = s2;
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) term(g, p[g * gstep + 16 * j]);
+            }
+            for (; k > 0; --k, p += 16) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) term(g, p[g * gstep]);
+            }
+            if (tail) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) term(g, p[g * gstep]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            sum[g] = row16_all<true>(sum[g]);
+            if (sub == 0) {
+                part[r + 4 * W * g] = mx[g];
+                part[64 + r + 4 * W * g] = -1.0f / sum[g];       // class cost = -softmax
+            }
         }
         __syncthreads();
-        float ms[8], ss[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { ms[r] = part[r * 64 + lane]; ss[r] = part[(8 + r) * 64 + lane]; }
-        float mx = ms[0];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) mx = fmaxf(mx, ms[r]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) ss[r] *= __builtin_amdgcn_exp2f((ms[r] - mx) * LOG2E);
-#pragma unroll
-        for (int h = 4; h >= 1; h /= 2)
-#pragma unroll
-            for (int r = 0; r < h; ++r) ss[r] = ss[2 * r] + ss[2 * r + 1];
-        ce_max = mx;
-        ce_scale = -1.0f / ss[0];       // class cost = -softmax
+        ce_max = part[lane];
+        ce_scale = part[64 + lane];
     }
 
     const int qs = set.q_stride;
@@ -423,10 +460,10 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     if (B > 65535 || S > 4096) return DM_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tile = C > 4;
-    // tile kernel: LDS = staged targets + softmax partials (softmax variant) + the logit tile
+    // tile kernel: LDS = staged targets + softmax statistics (softmax variant) + the logit tile
     const int mode = params->cls_mode == 0 ? 0 : (params->focal_gamma == 2.0f ? 1 : 2);
     const int tile_waves = g_tile_waves == 8 ? 8 : 4;
-    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 16 * sizeof(float) : 0) +
+    const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 2 * sizeof(float) : 0) +
                             (size_t)64 * C * sizeof(float);
     if (tile && tile_lds > 160 * 1024) return DM_E_UNSUPPORTED;
     typedef void (*TileFn)(const DmSetArray, const int, const int, const int, const int64_t *, const float *,
