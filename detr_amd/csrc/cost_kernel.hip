@@ -40,6 +40,9 @@ constexpr int TCHUNK = 64;   // targets staged per pass
 #ifndef DM_SMALL_NTST
 #define DM_SMALL_NTST 1
 #endif
+#ifndef DM_SMALL_ABL
+#define DM_SMALL_ABL 0
+#endif
 #ifndef DM_TILE_NTST
 #define DM_TILE_NTST 0
 #endif
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                                                             const int32_t *__restrict__ tgt_off, const DmParams prm,
                                                             float *__restrict__ cost, int32_t *status, const int tsplit)
 {
-    __shared__ TgtRec tg[TCHUNK];
+    __shared__ TgtRec tg[TCHUNK + 1];        // (+1: the record read ahead of the last one)
     typedef float vecq __attribute__((ext_vector_type(QPT)));
 
     const DmSet &set = sets.s[blockIdx.z];
@@ -110,10 +113,19 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
 #pragma unroll
     for (int i = 0; i < QPT; ++i) small_class_costs(x[i], C, prm, wc[i]);
 
+    // (opaque from here on: keeps the selection among the finished class costs from being rewritten
+    // as cost_class * (selection among the class costs), one more multiplication per pair)
+#pragma unroll
+    for (int i = 0; i < QPT; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) asm("" : "+v"(wc[i][c]));
+
     const int qs = set.q_stride;
-    float *out = cost + set.cost_off + (size_t)t0 * qs + q0;
+    // wave-uniform row pointer (scalar registers) + the thread's query as a 32-bit offset
+    float *row_out = cost + set.cost_off + (size_t)t0 * qs;
+    const unsigned qu = (unsigned)q0;
     // a QPT-wide store needs all its queries in range and natural alignment of the row start
-    const bool wide = (q0 + QPT <= Q) && (qs % QPT == 0) && ((reinterpret_cast<uintptr_t>(out) & (4 * QPT - 1)) == 0);
+    const bool wide = (q0 + QPT <= Q) && (qs % QPT == 0) && ((reinterpret_cast<uintptr_t>(row_out + q0) & (4 * QPT - 1)) == 0);
 
     for (int tc = 0; tc < T; tc += TCHUNK) {
         const int nt = min(TCHUNK, T - tc);
@@ -124,8 +136,9 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
         __syncthreads();
         if (q0 < Q) {
             TgtRec g = tg[0];
-            for (int i = 0; i < nt; ++i) {
-                const TgtRec gn = tg[min(i + 1, nt - 1)];     // next record in flight while this one is used
+            float *dst = row_out + (size_t)tc * qs;
+            auto entry = [&](const int i) {
+                const TgtRec gn = tg[i + 1];     // next record in flight while this one is used (the one past the end is never used)
                 // select by data, not by branch (the label is wave-uniform and the compiler would
                 // otherwise turn the selects into a scalar branch tree)
                 int l = g.label;
@@ -136,21 +149,44 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                     float wcls = wc[k][0];
 #pragma unroll
                     for (int c = 1; c < C; ++c) wcls = (l == c) ? wc[k][c] : wcls;
+#if DM_SMALL_ABL != 2
                     r[k] = pair_cost(p[k], g, wcls, prm.w_bbox, prm.w_giou);
+#endif
                 }
-                float *dst = out + (size_t)(tc + i) * qs;
-                if (QPT == 1 || wide) {
-#if DM_SMALL_NTST
-                    __builtin_nontemporal_store(r, reinterpret_cast<vecq *>(dst));
+#if DM_SMALL_ABL == 2
+                r[0] = g.area;
+#endif
+                if (QPT == 1) {
+#if DM_SMALL_ABL == 1
+                    if (r[0] == 123.456f) dst[qu] = r[0];
+#elif DM_SMALL_NTST
+                    // scalar row pointer + 32-bit lane offset, spelled out: the compiler would carry a
+                    // 64-bit address per lane through the loop instead
+                    asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(qu * 4u), "v"(r[0]), "s"(dst) : "memory");
 #else
-                    *reinterpret_cast<vecq *>(dst) = r;
+                    dst[qu] = r[0];
+#endif
+                } else if (wide) {
+#if DM_SMALL_NTST
+                    __builtin_nontemporal_store(r, reinterpret_cast<vecq *>(dst + qu));
+#else
+                    *reinterpret_cast<vecq *>(dst + qu) = r;
 #endif
                 } else {
 #pragma unroll
-                    for (int k = 0; k < QPT; ++k) if (q0 + k < Q) dst[k] = r[k];
+                    for (int k = 0; k < QPT; ++k) if (q0 + k < Q) dst[qu + k] = r[k];
                 }
                 g = gn;
+                dst += qs;
+            };
+            // (unrolled by hand: inline assembly counts as a convergent operation, which bars the
+            // compiler from unrolling a loop whose trip count it does not know)
+            int i = 0;
+            for (; i + 4 <= nt; i += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) entry(i + u);
             }
+            for (; i < nt; ++i) entry(i);
         }
     }
 }

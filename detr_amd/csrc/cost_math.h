@@ -86,15 +86,21 @@ __device__ __forceinline__ bool pred_valid(const PredBox &p)
 // `wcls` is cost_class * class cost.
 __device__ __forceinline__ float pair_cost(const PredBox &p, const TgtRec &g, float wcls, float w_bbox, float w_giou)
 {
-    const float l1 = ((fabsf(p.cx - g.cx) + fabsf(p.cy - g.cy)) + fabsf(p.w - g.w)) + fabsf(p.h - g.h);
-    const float iw = fast_max(fast_min(p.x1, g.x1) - fast_max(p.x0, g.x0), 0.0f);
-    const float ih = fast_max(fast_min(p.y1, g.y1) - fast_max(p.y0, g.y0), 0.0f);
-    const float inter = iw * ih;
+    // (two-element vectors: the differences of an axis pair are one packed instruction each)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 dc = f2{p.cx, p.cy} - f2{g.cx, g.cy};
+    const f2 ds = f2{p.w, p.h} - f2{g.w, g.h};
+    const float l1 = ((fabsf(dc.x) + fabsf(dc.y)) + fabsf(ds.x)) + fabsf(ds.y);
+    // per axis: (overlap, enclosing extent) = (min of the upper edges, max of them) - (max of the lower edges, min)
+    f2 ex = f2{fast_min(p.x1, g.x1), fast_max(p.x1, g.x1)} - f2{fast_max(p.x0, g.x0), fast_min(p.x0, g.x0)};
+    f2 ey = f2{fast_min(p.y1, g.y1), fast_max(p.y1, g.y1)} - f2{fast_max(p.y0, g.y0), fast_min(p.y0, g.y0)};
+    // the overlap is clamped at zero; the enclosing box is never negative for valid boxes, so the
+    // reference's clamp is a no-op there
+    ex.x = fast_max(ex.x, 0.0f);
+    ey.x = fast_max(ey.x, 0.0f);
+    const f2 areas = ex * ey;
+    const float inter = areas.x, earea = areas.y;
     const float uni = (p.area + g.area) - inter;
-    // enclosing box: never negative for valid boxes, so the reference's clamp is a no-op
-    const float ew = fast_max(p.x1, g.x1) - fast_min(p.x0, g.x0);
-    const float eh = fast_max(p.y1, g.y1) - fast_min(p.y0, g.y0);
-    const float earea = ew * eh;
     // -giou = -(inter/uni - (earea - uni)/earea) = (1 - inter/uni) - uni/earea
     const float neg_giou = __builtin_fmaf(-uni, __builtin_amdgcn_rcpf(earea),
                                           __builtin_fmaf(-inter, __builtin_amdgcn_rcpf(uni), 1.0f));

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--targets", type=int, default=None, help="the same number of targets for every image")
     ap.add_argument("--which", default="cost,lap,both,fused")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-shape knob, e.g. lap_kernel=3, lap_max_waves=5, cost_tsplit=2, tile_waves=8")
@@ -34,7 +35,10 @@ def main():
     for kv in args.knob:
         name, value = kv.split("=")
         detr_amd._lib.set_knob(name, int(value))
-    wl, sets, targets = synth.make_workload(args.workload, device=dev, batch=args.batch)
+    counts = None
+    if args.targets is not None:
+        counts = [args.targets] * (args.batch or synth.WORKLOADS[args.workload].batch)
+    wl, sets, targets = synth.make_workload(args.workload, device=dev, batch=args.batch, counts=counts)
     packed = PackedTargets(targets, dev)
     S, B, M = len(sets), packed.batch, packed.total
     C = wl.n_logits
