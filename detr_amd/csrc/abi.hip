@@ -155,8 +155,9 @@ extern "C" int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, cons
     if (S < 0 || B < 0 || C < 1 || max_T < 0 || !params || !status || !packed) return DM_E_INVALID_ARG;
     *packed = 0;
     if (S == 0 || B == 0) return DM_OK;
-    if (!sets || !pointers || !meta || !labels_buf || !boxes_buf || !meta_buf || !workspace || !src_out || !tgt_out)
-        return DM_E_INVALID_ARG;
+    if (!sets || !pointers || !meta || !workspace || !src_out || !tgt_out) return DM_E_INVALID_ARG;
+    const bool have_buffers = labels_buf && boxes_buf && meta_buf;
+    if (!have_buffers && (labels_buf || boxes_buf || meta_buf)) return DM_E_INVALID_ARG;
     bool direct = !g_no_fuse && !g_no_direct && B <= dm::DIRECT_MAX_IMAGES && max_T > 0 && dm::lap_can_fuse(C, max_T) && S <= 4096;
     if (direct) {
         for (int s = 0; s < S; ++s)
@@ -167,6 +168,7 @@ extern "C" int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, cons
         for (int s = 0; s < S; ++s) direct = direct && !needs_cost[s];      // every set in a fused launch
     }
     if (!direct) {
+        if (!have_buffers) return DM_NEED_BUFFERS;       // nothing launched
         int rc = dm_pack_targets(pointers, meta, B, labels_buf, boxes_buf, meta_buf, stream);
         if (rc != DM_OK) return rc;
         *packed = 1;
@@ -189,7 +191,7 @@ extern "C" int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, cons
     fin.table.offsets[B] = meta[B];
     if (g_profile) { (void)hipEventRecord(g_ev[0], st); (void)hipEventRecord(g_ev[1], st); }
     // (tgt_off / order are not read by a launch that has the table: every set of this call is in one)
-    int rc = dm::lap_run(sets, S, B, workspace, meta_buf, meta_buf + B + 1, max_T, src_out, tgt_out, flat_out, status, st,
+    int rc = dm::lap_run(sets, S, B, workspace, nullptr, nullptr, max_T, src_out, tgt_out, flat_out, status, st,
                          &fin, workspace);
     if (g_profile) { (void)hipEventRecord(g_ev[2], st); g_ev_valid = rc == DM_OK; }
     return rc;

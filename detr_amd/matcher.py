@@ -26,6 +26,7 @@ from ._lib import DmParams, DmSet, lib
 Indices = List[Tuple[torch.Tensor, torch.Tensor]]
 
 _split_with_sizes = torch.ops.aten.unsafe_split_with_sizes.default
+_raw_stream = torch._C._cuda_getCurrentRawStream       # (device index) -> the current stream's handle, no Stream object
 
 try:        # bulk creation of the per-image index views (csrc/index_views.cpp, built by build_ext.py)
     from . import _index_views
@@ -94,30 +95,36 @@ class PackedTargets:
         self.sizes, self.total, self.max_t, pointers, tensors, versions, self.offsets_list, meta = scan
         self._scanned = (tensors, versions)       # keeps the tensors (and so the pointers) alive
         self.batch = B = len(self.sizes)
-        M = max(self.total, 1)
-        # one device buffer [boxes f32 4M | labels int64 M | meta int32 2B+1], every part aligned for its type
-        off_labels = 16 * M
-        off_meta = off_labels + 8 * M
-        buf = torch.empty(off_meta + 4 * (2 * B + 1), dtype=torch.uint8, device=device)
-        # (the tensors `labels`, `boxes`, `meta` are views of this buffer, made when somebody asks for them:
-        # the matcher itself only needs the addresses)
-        self._buf, self._layout = buf, (M, off_labels, off_meta)
-        base = buf.data_ptr()
-        self._pointers = (base + off_labels, base, base + off_meta, base + off_meta + 4 * (B + 1))
         self._unpacked = (pointers, meta, index)      # what dm_pack_targets needs; None once the buffer is filled
+        self._pointers = None
         if not defer:
             self._ensure_packed()
+
+    def _pack_buffer(self):
+        """One device buffer [boxes f32 4M | labels int64 M | meta int32 2B+1], every part aligned for its type;
+        allocated when the packed form is first needed.  Returns the addresses (labels, boxes, offsets, order)."""
+        if self._pointers is None:
+            B, M = self.batch, max(self.total, 1)
+            off_labels = 16 * M
+            off_meta = off_labels + 8 * M
+            buf = torch.empty(off_meta + 4 * (2 * B + 1), dtype=torch.uint8, device=self.device)
+            # (the tensors `labels`, `boxes`, `meta` are views of this buffer, made when somebody asks for them:
+            # the matcher itself only needs the addresses)
+            self._buf, self._layout = buf, (M, off_labels, off_meta)
+            base = buf.data_ptr()
+            self._pointers = (base + off_labels, base, base + off_meta, base + off_meta + 4 * (B + 1))
+        return self._pointers
 
     def _ensure_packed(self):
         pending = self.__dict__.get("_unpacked")
         if pending is None:
             return
         pointers, meta, index = pending
+        labels_ptr, boxes_ptr, meta_ptr, _ = self._pack_buffer()
         self._unpacked = None
         M, off_labels, off_meta = self._layout
         if self.total == 0:
             self._buf[:off_meta].zero_()
-        labels_ptr, boxes_ptr, meta_ptr, _ = self._pointers
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if index == torch.cuda.current_device():
             rc = lib.dm_pack_targets(pointers, meta, self.batch, labels_ptr, boxes_ptr, meta_ptr, stream)
@@ -128,7 +135,7 @@ class PackedTargets:
 
     def __getattr__(self, name):
         # only reached for attributes that are not set: the lazily made views of the pack kernel's buffer
-        if name in ("labels", "boxes", "meta") and "_buf" in self.__dict__:
+        if name in ("labels", "boxes", "meta") and "_scanned" in self.__dict__ and self._scanned is not None:
             self._ensure_packed()
             M, off_labels, off_meta = self._layout
             buf = self._buf
@@ -469,22 +476,29 @@ class HungarianMatcher(torch.nn.Module):
             status_ptr = src_ptr + 16 * SM
             flat_ptr = status_ptr + 8 if flat else None
             self.last_status = out[2 * SM:2 * SM + 1]
-        stream = torch.cuda.current_stream(device).cuda_stream
+        current = torch.cuda.current_device()
+        on_current = device.index is None or device.index == current
+        stream = _raw_stream(current if device.index is None else device.index)
         entry = lib.dm_match_flat_f32 if want_cost else lib.dm_match_fused_f32
         pending = packed.__dict__.get("_unpacked")
         if pending is not None and not want_cost:
             # targets not packed yet: one call that packs and matches -- or, when the step is one fused kernel,
             # only matches, the kernel reading the targets where they are
             pointers, meta, _ = pending
-            labels_ptr, boxes_ptr, meta_ptr, _ = packed._pointers
             did_pack = ctypes.c_int(0)
-            args = (sets, S, batch, C, pointers, meta, packed.max_t, self._params_ref(), labels_ptr, boxes_ptr, meta_ptr,
-                    cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream, ctypes.byref(did_pack))
-            if device.index is None or device.index == torch.cuda.current_device():
-                rc = lib.dm_match_targets_f32(*args)
-            else:
-                with torch.cuda.device(device):
+            while True:
+                # (room for the packed form is only allocated when the call says it has to pack)
+                labels_ptr, boxes_ptr, meta_ptr = packed._pointers[:3] if packed._pointers is not None else (None, None, None)
+                args = (sets, S, batch, C, pointers, meta, packed.max_t, self._params_ref(), labels_ptr, boxes_ptr, meta_ptr,
+                        cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream, ctypes.byref(did_pack))
+                if on_current:
                     rc = lib.dm_match_targets_f32(*args)
+                else:
+                    with torch.cuda.device(device):
+                        rc = lib.dm_match_targets_f32(*args)
+                if rc != _lib.NEED_BUFFERS or packed._pointers is not None:
+                    break
+                packed._pack_buffer()
             _lib.check(rc, "dm_match_targets_f32")
             if did_pack.value:
                 if packed.total == 0:
@@ -492,7 +506,7 @@ class HungarianMatcher(torch.nn.Module):
                 packed._unpacked = None
             return out, queries, cost, strides
         labels_ptr, boxes_ptr, offsets_ptr, order_ptr = packed.device_pointers()
-        if device.index is None or device.index == torch.cuda.current_device():
+        if on_current:
             rc = entry(sets, S, batch, C, labels_ptr, boxes_ptr, offsets_ptr, order_ptr, packed.max_t,
                        self._params_ref(), cost.data_ptr(), src_ptr, src_ptr + 8 * SM, flat_ptr, status_ptr, stream)
         else:
@@ -534,13 +548,16 @@ class HungarianMatcher(torch.nn.Module):
             host = torch.empty(n, dtype=torch.int64, pin_memory=True)
             direct = own and self.indices_to_host and device.index in (None, torch.cuda.current_device())
             if direct:
-                host[0] = 0                  # the status word: the kernels only ever OR bits into it
+                status_word = ctypes.c_int64.from_address(host.data_ptr())
+                status_word.value = 0        # the kernels only ever OR bits into it
                 out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=True, host_out=host)
+                done = self._done_event(device)
+                done.record()                # current device, current stream: where the kernels went
             else:
                 out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=own, want_cost=return_cost)
                 host.copy_(out[:n], non_blocking=True)
-            done = self._done_event(device)
-            done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
+                done = self._done_event(device)
+                done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
             # the per-image views depend on shapes only: build them while the GPU is working
             if own:
                 result, status_at = self._split(host[1:], S, M, sizes, queries, packed.offsets_list), 0
@@ -550,7 +567,7 @@ class HungarianMatcher(torch.nn.Module):
             # stream synchronisation, which is only the fallback
             if not done.query():
                 done.synchronize()
-            bits = int(host[status_at]) & 0xFFFFFFFF
+            bits = (status_word.value if direct else int(host[status_at])) & 0xFFFFFFFF
             if bits:
                 if own and not direct:
                     out[:1].zero_()          # the kept buffer's status word, for the next call

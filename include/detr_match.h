@@ -50,6 +50,7 @@ extern "C" {
 #define DM_E_INVALID_ARG (-1)
 #define DM_E_LAUNCH (-2)       /* a HIP call failed; dm_last_hip_error() has the text */
 #define DM_E_UNSUPPORTED (-3)  /* problem exceeds a documented limit */
+#define DM_NEED_BUFFERS 1      /* dm_match_targets_f32 only: nothing was launched, call again with the buffers */
 
 /* status-word bits (device int32), and the exception the reference raises for each */
 #define DM_ST_LABEL_RANGE 1     /* IndexError: label outside [-C, C)   (matcher.py:73,81) */
@@ -171,7 +172,9 @@ int dm_match_fused_f32(const DmSet *sets, int S, int B, int C,
  * through the pointers (they travel, with offsets and order, as kernel arguments): no packed copy, no second launch.
  *   pointers, meta              as for dm_pack_targets
  *   labels_buf, boxes_buf, meta_buf   device room for the packed targets (M int64, M x 4 float 16-byte aligned,
- *                               2 * B + 1 int32); filled only when the call had to pack: *packed says so
+ *                               2 * B + 1 int32); filled only when the call had to pack: *packed says so.
+ *                               All three may be NULL: a call that would have to pack then launches nothing
+ *                               and returns DM_NEED_BUFFERS
  *   the rest                    as for dm_match_fused_f32
  * The per-image tensors must stay alive and unchanged until the call's work on `stream` has completed.
  */

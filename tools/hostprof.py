@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Where the host time of one match_many step goes (cProfile + coarse timers)."""
-import cProfile
+"""Cost of the host-side pieces of one match_many step, each timed alone (us per call, GPU box's host)."""
+import ctypes
 import os
-import pstats
 import sys
 import time
 
@@ -11,53 +10,63 @@ import torch
 
 import detr_amd
 from detr_amd import synth
+from detr_amd.matcher import PackedTargets, _index_views
+from detr_amd._lib import lib
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-wl, sets, targets = synth.make_workload(name, device="cuda")
+wl, sets, targets = synth.make_workload(sys.argv[1] if len(sys.argv) > 1 else "cfg2", device="cuda")
 m = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+dev = torch.device("cuda", 0)
+m.match_many(sets, targets)
+torch.cuda.synchronize()
+pool = [[{k: v[:] for k, v in t.items()} for t in targets] for _ in range(4)]
+packed = PackedTargets(targets, dev, defer=True)
+S, B, M = len(sets), packed.batch, packed.total
+N = 2000
+
+
+def bench(label, fn):
+    for _ in range(50):
+        fn()
+    t = time.perf_counter()
+    for _ in range(N):
+        fn()
+    print(f"{label:44s} {(time.perf_counter() - t) / N * 1e6:7.2f} us")
+
+
+k = [0]
+def nxt():
+    k[0] += 1
+    return pool[k[0] & 3]
+
+bench("same_targets (miss)", lambda: packed.same_targets(nxt()))
+bench("same_targets (hit)", lambda: packed.same_targets(targets))
+bench("scan_targets", lambda: _index_views.scan_targets(nxt(), 0))
+bench("PackedTargets(defer=True)", lambda: PackedTargets(nxt(), dev, defer=True))
+bench("torch.empty(device uint8)", lambda: torch.empty(40000, dtype=torch.uint8, device=dev))
+n = 2 * S * M + 1
+bench("torch.empty(pinned int64)", lambda: torch.empty(n, dtype=torch.int64, pin_memory=True))
+host = torch.empty(n, dtype=torch.int64, pin_memory=True)
+def z():
+    host[0] = 0
+bench("host[0] = 0", z)
+bench("scan_outputs", lambda: _index_views.scan_outputs(sets, B, M))
+bench("current_stream().cuda_stream", lambda: torch.cuda.current_stream(dev).cuda_stream)
+bench("_params_ref", m._params_ref)
+ev = torch.cuda.Event()
+st = torch.cuda.current_stream(dev)
+bench("event.record", lambda: ev.record(st))
+torch.cuda.synchronize()
+bench("event.query", ev.query)
+bench("int(host[0])", lambda: int(host[0]))
+bench("dm_strerror (a trivial ctypes call)", lambda: lib.dm_strerror(0))
+def launch():
+    m._launch(sets, m._packed_for(nxt(), dev), own_buffers=True, host_out=host)
 for _ in range(20):
-    m.match_many(sets, targets)
+    launch()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-N = 200
-for _ in range(N):
-    m.match_many(sets, targets)
+t = time.perf_counter()
+for _ in range(300):
+    launch()
+dt = (time.perf_counter() - t) / 300 * 1e6
 torch.cuda.synchronize()
-print("us/step", (time.perf_counter() - t0) / N * 1e6)
-packed = detr_amd.PackedTargets(targets, torch.device("cuda", 0))
-t0 = time.perf_counter()
-for _ in range(N):
-    m.match_many(sets, packed)
-torch.cuda.synchronize()
-print("us/step with pre-packed targets", (time.perf_counter() - t0) / N * 1e6)
-t0 = time.perf_counter()
-for _ in range(N):
-    m.match_many(sets, packed, device_indices=True)
-torch.cuda.synchronize()
-print("us/step pre-packed, device indices", (time.perf_counter() - t0) / N * 1e6)
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(N):
-    m.match_many(sets, targets)
-pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
-t0 = time.perf_counter()
-for _ in range(N):
-    m.match_flat(sets, packed)
-torch.cuda.synchronize()
-print("us/step pre-packed, match_flat", (time.perf_counter() - t0) / N * 1e6)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(N):
-    m.match_flat(sets, packed)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print("match_flat host us/call", (t1 - t0) / N * 1e6, " drain us", (t2 - t1) * 1e6)
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(N):
-    m.match_flat(sets, packed)
-pr.disable()
-torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+print(f"{'_packed_for + _launch, back to back (queue full)':44s} {dt:7.2f} us")
