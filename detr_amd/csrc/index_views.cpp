@@ -20,12 +20,15 @@
 // per image.  They only read tensor metadata; anything unusual (other dtypes, non-contiguous tensors,
 // mismatched lengths) is reported as None and the Python code takes its general path, which raises the
 // reference's exceptions.
+// launch_targets is the usual step's host side in one call: output scan, pinned result tensor, the library's
+// entry point (through its address).
 // No GPU code here; the kernels are in the .hip files.
 #include <Python.h>
 
 #include <algorithm>
 #include <vector>
 
+#include <ATen/ATen.h>
 #include <ATen/core/Tensor.h>
 #include <c10/core/TensorImpl.h>
 #include <torch/csrc/autograd/python_variable.h>
@@ -298,20 +301,22 @@ static_assert(sizeof(SetRecord) == 40, "must match DmSet");
 // None unless every set has float32 contiguous pred_logits [batch, Q, C] and pred_boxes [batch, Q, 4] (16-byte
 // aligned) on one CUDA device with one C.  Cost regions are laid out one after the other, row stride = Q
 // rounded up to 32; index regions at s * num_targets.
-PyObject *scan_outputs(PyObject *, PyObject *args)
-{
-    PyObject *outputs;
-    long long batch, M;
-    int allow_host = 0;      // tests only: accept host tensors
-    if (!PyArg_ParseTuple(args, "OLL|p", &outputs, &batch, &M, &allow_host)) return nullptr;
-    PyObject *fast = PySequence_Fast(outputs, "outputs must be a sequence");
-    if (!fast) return nullptr;
-    const Py_ssize_t S = PySequence_Fast_GET_SIZE(fast);
-    std::vector<SetRecord> recs((size_t)S);
-    PyObject *queries = PyList_New(S);
-    bool ok = queries != nullptr && S > 0;
+struct OutputScan {
+    std::vector<SetRecord> recs;
+    PyObject *queries = nullptr;      // new reference, list[int]
     int64_t cost_off = 0, C = 0;
     int device_index = -1;
+};
+
+// false (with or without a Python error set) unless every set is of the usual form
+bool scan_output_sets(PyObject *outputs, long long batch, long long M, bool allow_host, OutputScan &r)
+{
+    PyObject *fast = PySequence_Fast(outputs, "outputs must be a sequence");
+    if (!fast) return false;
+    const Py_ssize_t S = PySequence_Fast_GET_SIZE(fast);
+    r.recs.resize((size_t)S);
+    r.queries = PyList_New(S);
+    bool ok = r.queries != nullptr && S > 0;
     for (Py_ssize_t s = 0; ok && s < S; ++s) {
         PyObject *d = PySequence_Fast_GET_ITEM(fast, s);
         const at::Tensor *l = dict_tensor(d, g_key_logits), *x = dict_tensor(d, g_key_pboxes);
@@ -322,28 +327,112 @@ PyObject *scan_outputs(PyObject *, PyObject *args)
              x->is_contiguous() && (l->device().is_cuda() || allow_host) && x->device() == l->device() &&
              (reinterpret_cast<uintptr_t>(x->data_ptr()) & 15) == 0;
         if (!ok) break;
-        if (s == 0) { C = l->size(2); device_index = l->device().index(); }
-        ok = l->size(2) == C && l->device().index() == device_index;
+        if (s == 0) { r.C = l->size(2); r.device_index = l->device().index(); }
+        ok = l->size(2) == r.C && l->device().index() == r.device_index;
         if (!ok) break;
         const int64_t Q = l->size(1), stride = (Q + 31) / 32 * 32;
-        recs[(size_t)s] = SetRecord{l->data_ptr(), x->data_ptr(), cost_off, (int64_t)s * M, (int32_t)Q, (int32_t)stride};
-        cost_off += M * stride;
-        PyList_SET_ITEM(queries, s, PyLong_FromLongLong(Q));
+        r.recs[(size_t)s] = SetRecord{l->data_ptr(), x->data_ptr(), r.cost_off, (int64_t)s * M, (int32_t)Q, (int32_t)stride};
+        r.cost_off += M * stride;
+        PyList_SET_ITEM(r.queries, s, PyLong_FromLongLong(Q));
     }
     Py_DECREF(fast);
     if (!ok) {
-        Py_XDECREF(queries);
+        Py_XDECREF(r.queries);
+        r.queries = nullptr;
+    }
+    return ok;
+}
+
+PyObject *scan_outputs(PyObject *, PyObject *args)
+{
+    PyObject *outputs;
+    long long batch, M;
+    int allow_host = 0;      // tests only: accept host tensors
+    if (!PyArg_ParseTuple(args, "OLL|p", &outputs, &batch, &M, &allow_host)) return nullptr;
+    OutputScan r;
+    if (!scan_output_sets(outputs, batch, M, allow_host != 0, r)) {
         if (PyErr_Occurred()) return nullptr;
         Py_RETURN_NONE;
     }
-    PyObject *rb = PyBytes_FromStringAndSize(reinterpret_cast<const char *>(recs.data()), (Py_ssize_t)(recs.size() * sizeof(SetRecord)));
-    return Py_BuildValue("(iLNNL)", device_index, (long long)C, queries, rb, (long long)cost_off);
+    PyObject *rb = PyBytes_FromStringAndSize(reinterpret_cast<const char *>(r.recs.data()), (Py_ssize_t)(r.recs.size() * sizeof(SetRecord)));
+    return Py_BuildValue("(iLNNL)", r.device_index, (long long)r.C, r.queries, rb, (long long)r.cost_off);
+}
+
+// dm_match_targets_f32 of include/detr_match.h, called through its address (this module does not link the
+// kernel library)
+typedef int (*MatchTargetsFn)(const void *sets, int S, int B, int C, const uint64_t *pointers, const int32_t *meta,
+                              int max_T, const void *params, int64_t *labels_buf, float *boxes_buf, int32_t *meta_buf,
+                              float *workspace, int64_t *src_out, int64_t *tgt_out, int64_t *flat_out, int32_t *status,
+                              void *stream, int *packed);
+
+// launch_targets(outputs, batch, M, max_t, pointers, meta, entry, params, workspace, workspace_floats, stream,
+//                device_index)
+// One matcher step for a caller that wants the reference's CPU tuples: checks the output sets, allocates the
+// pinned host tensor [status | src (S*M) | tgt (S*M)] the kernels store their indices into, clears its status
+// word and calls dm_match_targets_f32 (entry: its address; params: address of the DmParams; pointers, meta:
+// from scan_targets; workspace: device floats for the rows of a cost block that do not fit in LDS) without
+// buffers for packed targets.  Returns
+//   None                        unusual output sets, or not on device `device_index`: nothing done
+//   int                         floats of workspace the call needs, more than it was handed: nothing done
+//   (host, queries, rc)         rc as returned by the entry point; 1 (DM_NEED_BUFFERS): nothing was launched
+PyObject *launch_targets(PyObject *, PyObject *args)
+{
+    PyObject *outputs, *pointers, *meta;
+    long long batch, M, max_t, ws_floats;
+    unsigned long long entry, params, workspace, stream;
+    int device_index;
+    if (!PyArg_ParseTuple(args, "OLLLSSKKKLKi", &outputs, &batch, &M, &max_t, &pointers, &meta, &entry, &params,
+                          &workspace, &ws_floats, &stream, &device_index))
+        return nullptr;
+    if (batch < 1 || M < 0 || batch > INT32_MAX / 2 || max_t > INT32_MAX || !entry || !params ||
+        PyBytes_GET_SIZE(pointers) != 16 * batch || PyBytes_GET_SIZE(meta) != 4 * (2 * batch + 1)) {
+        PyErr_SetString(PyExc_ValueError, "launch_targets: inconsistent arguments");
+        return nullptr;
+    }
+    OutputScan r;
+    if (!scan_output_sets(outputs, batch, M, false, r)) {
+        if (PyErr_Occurred()) return nullptr;
+        Py_RETURN_NONE;
+    }
+    const int64_t S = (int64_t)r.recs.size(), SM = S * M;
+    if (r.device_index != device_index || S > INT32_MAX || r.C > INT32_MAX) {
+        Py_DECREF(r.queries);
+        Py_RETURN_NONE;
+    }
+    const int64_t need = r.cost_off > 1 ? r.cost_off : 1;
+    if (need > ws_floats || !workspace) {
+        Py_DECREF(r.queries);
+        return PyLong_FromLongLong(need);
+    }
+    at::Tensor host;
+    try {
+        host = at::empty({2 * SM + 1}, at::TensorOptions().dtype(at::kLong).pinned_memory(true));
+    } catch (const std::exception &e) {
+        Py_DECREF(r.queries);
+        PyErr_SetString(PyExc_RuntimeError, e.what());
+        return nullptr;
+    }
+    int64_t *base = host.data_ptr<int64_t>();
+    base[0] = 0;        // the status word: the kernels only ever OR bits into it
+    int packed = 0;
+    const int rc = reinterpret_cast<MatchTargetsFn>(entry)(
+        r.recs.data(), (int)S, (int)batch, (int)r.C, reinterpret_cast<const uint64_t *>(PyBytes_AS_STRING(pointers)),
+        reinterpret_cast<const int32_t *>(PyBytes_AS_STRING(meta)), (int)max_t, reinterpret_cast<const void *>(params),
+        nullptr, nullptr, nullptr, reinterpret_cast<float *>(workspace), base + 1, base + 1 + SM, nullptr,
+        reinterpret_cast<int32_t *>(base), reinterpret_cast<void *>(stream), &packed);
+    PyObject *ht = THPVariable_Wrap(host);
+    if (!ht) {
+        Py_DECREF(r.queries);
+        return nullptr;
+    }
+    return Py_BuildValue("(NNi)", ht, r.queries, rc);
 }
 
 PyMethodDef methods[] = {
     {"scan_targets", scan_targets, METH_VARARGS, "metadata and data pointers of a list of target dicts"},
     {"same_targets", same_targets, METH_VARARGS, "are these the unchanged tensors of an earlier scan_targets"},
     {"scan_outputs", scan_outputs, METH_VARARGS, "checked DmSet descriptors of a list of output dicts"},
+    {"launch_targets", launch_targets, METH_VARARGS, "pinned index tensor + one dm_match_targets_f32 call"},
     {"index_pairs", index_pairs, METH_VARARGS, "flat index buffer -> per set, per image (src, tgt) views"},
     {"pool_size", pool_size, METH_NOARGS, "tensor objects kept for recycling"},
     {"clear_pool", clear_pool, METH_NOARGS, "drop the recycled tensor objects"},

@@ -26,6 +26,7 @@ from ._lib import DmParams, DmSet, lib
 Indices = List[Tuple[torch.Tensor, torch.Tensor]]
 
 _split_with_sizes = torch.ops.aten.unsafe_split_with_sizes.default
+_TARGETS_ENTRY = ctypes.cast(lib.dm_match_targets_f32, ctypes.c_void_p).value
 _raw_stream = torch._C._cuda_getCurrentRawStream       # (device index) -> the current stream's handle, no Stream object
 
 try:        # bulk creation of the per-image index views (csrc/index_views.cpp, built by build_ext.py)
@@ -348,6 +349,7 @@ class HungarianMatcher(torch.nn.Module):
         self._buffers = {}
         self._packed = None
         self._params_cache = None
+        self._skip_fast = 0
 
     def __getstate__(self):
         # per-device events and buffers, the packed targets and the last status view belong to this
@@ -362,7 +364,7 @@ class HungarianMatcher(torch.nn.Module):
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None),
+        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None), ("_skip_fast", 0),
                             ("through_ops", False), ("indices_to_host", True)):
             self.__dict__.setdefault(name, value)
 
@@ -384,7 +386,7 @@ class HungarianMatcher(torch.nn.Module):
         cached = self._params_cache
         if cached is None or cached[0] != key:
             params = self._params()
-            cached = self._params_cache = (key, params, ctypes.byref(params))
+            cached = self._params_cache = (key, params, ctypes.byref(params), ctypes.addressof(params))
         return cached[2]
 
     @torch.no_grad()
@@ -425,6 +427,38 @@ class HungarianMatcher(torch.nn.Module):
         if n_cost and (ws["cost"] is None or ws["cost"].shape[0] < n_cost):
             ws["cost"] = torch.empty(n_cost, dtype=torch.float32, device=device)
         return ws
+
+    def _launch_to_host(self, outputs_list, packed: PackedTargets, device):
+        """The usual step in one call of the host helper: output sets checked, pinned result tensor
+        [status | src | tgt] made, dm_match_targets_f32 called on the targets where they are.  Returns
+        (host tensor, queries per set), or None when the step is not of that kind (the general path then decides)."""
+        pending = packed.__dict__.get("_unpacked")
+        if pending is None or _index_views is None:
+            return None
+        if self._skip_fast > 0:
+            self._skip_fast -= 1
+            return None
+        index = torch.cuda.current_device()
+        ws = self._buffers.get(index)
+        cost = ws["cost"] if ws is not None else None
+        self._params_ref()
+        while True:
+            r = _index_views.launch_targets(outputs_list, packed.batch, packed.total, packed.max_t, pending[0], pending[1],
+                                            _TARGETS_ENTRY, self._params_cache[3], cost.data_ptr() if cost is not None else 0,
+                                            cost.shape[0] if cost is not None else 0, _raw_stream(index), index)
+            if r is None:
+                return None
+            if type(r) is int:          # a larger workspace is needed: nothing was launched
+                cost = self._workspace(device, 0, r)["cost"]
+                continue
+            break
+        host, queries, rc = r
+        if rc == _lib.NEED_BUFFERS:     # the step has to pack its targets: not this path's business for a while
+            self._skip_fast = 64
+            return None
+        _lib.check(rc, "dm_match_targets_f32")
+        self.last_status = None
+        return host, queries
 
     def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False, own_buffers: bool = False,
                 want_cost: bool = False, host_out: Optional[torch.Tensor] = None):
@@ -545,15 +579,22 @@ class HungarianMatcher(torch.nn.Module):
         else:
             own = not (return_cost or self.through_ops or torch.compiler.is_compiling())
             n = 2 * S * M + 1
-            host = torch.empty(n, dtype=torch.int64, pin_memory=True)
             direct = own and self.indices_to_host and device.index in (None, torch.cuda.current_device())
-            if direct:
+            fast = self._launch_to_host(outputs_list, packed, device) if direct else None
+            if fast is not None:
+                host, queries = fast
+                status_word = ctypes.c_int64.from_address(host.data_ptr())
+                done = self._done_event(device)
+                done.record()
+            elif direct:
+                host = torch.empty(n, dtype=torch.int64, pin_memory=True)
                 status_word = ctypes.c_int64.from_address(host.data_ptr())
                 status_word.value = 0        # the kernels only ever OR bits into it
                 out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=True, host_out=host)
                 done = self._done_event(device)
                 done.record()                # current device, current stream: where the kernels went
             else:
+                host = torch.empty(n, dtype=torch.int64, pin_memory=True)
                 out, queries, cost, strides = self._launch(outputs_list, packed, own_buffers=own, want_cost=return_cost)
                 host.copy_(out[:n], non_blocking=True)
                 done = self._done_event(device)

@@ -59,6 +59,32 @@ torch.cuda.synchronize()
 bench("event.query", ev.query)
 bench("int(host[0])", lambda: int(host[0]))
 bench("dm_strerror (a trivial ctypes call)", lambda: lib.dm_strerror(0))
+# the C call alone (ctypes marshalling + planning + hipLaunchKernel), prepared arguments, 100 launches in the queue
+import detr_amd.matcher as mm
+pk = m._packed_for(targets, dev)
+scan = _index_views.scan_outputs(sets, B, M)
+_, C, queries, setbytes, cost_off = scan
+ws = m._workspace(dev, 0, max(cost_off, 1))
+pointers, meta, _ = PackedTargets(pool[0], dev, defer=True)._unpacked
+did = ctypes.c_int(0)
+stream = mm._raw_stream(0)
+sp = host.data_ptr()
+args = (setbytes, S, B, C, pointers, meta, pk.max_t, m._params_ref(), None, None, None, ws["cost"].data_ptr(),
+        sp + 8, sp + 8 + 8 * S * M, None, sp, stream, ctypes.byref(did))
+for _ in range(5):
+    lib.dm_match_targets_f32(*args)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(100):
+    lib.dm_match_targets_f32(*args)
+dt = (time.perf_counter() - t) / 100 * 1e6
+torch.cuda.synchronize()
+print(f"{'dm_match_targets_f32 call (host side)':44s} {dt:7.2f} us")
+arr = (detr_amd._lib.DmSet * S).from_buffer_copy(setbytes)
+need = (ctypes.c_ubyte * 4096)()
+bench("data_ptr()", host.data_ptr)
+
+
 def launch():
     m._launch(sets, m._packed_for(nxt(), dev), own_buffers=True, host_out=host)
 for _ in range(20):
