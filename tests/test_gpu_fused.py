@@ -157,3 +157,54 @@ def test_indices_stored_to_host_memory_equal_copied_indices(name, batch):
         with pytest.raises(IndexError):
             matcher.match_many(sets, bad)
         _assert_identical(direct, matcher.match_many(sets, targets))
+
+
+def test_one_call_launch_equals_the_general_path():
+    """The usual step goes through ONE call of the host helper (output scan, pinned result tensor, entry point);
+    everything else through the Python path.  Same tuples; the helper asks for a larger workspace instead of
+    launching into a small one, and a step that has to pack its targets leaves that path alone for a while."""
+    import detr_amd
+    import detr_amd.matcher as mm
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg2", device="cuda", batch=16)
+    fast = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    calls = []
+    real = mm._index_views.launch_targets
+
+    class Spy:
+        def __getattr__(self, name):
+            return getattr(mm._index_views_real, name)
+
+        @staticmethod
+        def launch_targets(*a):
+            r = real(*a)
+            calls.append(r if type(r) is int else (None if r is None else r[2]))
+            return r
+
+    mm._index_views_real, mm._index_views = mm._index_views, Spy()
+    try:
+        a = fast.match_many(sets, targets)
+        assert len(calls) == 2 and calls[0] > 0 and calls[1] == 0        # workspace request, then the launch
+        b = fast.match_many(sets[:2], targets)                           # smaller step, workspace large enough
+        assert calls[2:] == [0]
+        # 128 images: more than the kernel-argument table holds -> the call reports that it has to pack
+        wl5, sets5, targets5 = synth.make_workload("cfg5", device="cuda", batch=128)
+        big = detr_amd.HungarianMatcher(**wl5.matcher_kwargs)
+        del calls[:]
+        c = big.match_many(sets5[:2], targets5)
+        assert calls[-1] == detr_amd._lib.NEED_BUFFERS and big._skip_fast == 64
+        n = len(calls)
+        big.match_many(sets5[:2], targets5[:-1] + [dict(targets5[-1], labels=targets5[-1]["labels"].clone())])
+        assert len(calls) == n and big._skip_fast == 63                  # not tried again right away
+    finally:
+        mm._index_views = mm._index_views_real
+        del mm._index_views_real
+    slow = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    helper, mm._index_views = mm._index_views, None
+    try:
+        _assert_identical(a, slow.match_many(sets, targets))
+        _assert_identical(b, slow.match_many(sets[:2], targets))
+        _assert_identical(c, detr_amd.HungarianMatcher(**wl5.matcher_kwargs).match_many(sets5[:2], targets5))
+    finally:
+        mm._index_views = helper

@@ -282,3 +282,20 @@ def test_tensor_scans_of_the_host_helper():
     assert iv.scan_outputs([{"pred_logits": torch.rand(3, 10, 2).double(), "pred_boxes": torch.rand(3, 10, 4)}], 3, 8, True) is None
     assert iv.scan_outputs([outs[0], {"pred_logits": torch.rand(3, 10, 3), "pred_boxes": torch.rand(3, 10, 4)}], 3, 8, True) is None
     assert iv.scan_outputs([{"pred_logits": torch.rand(3, 10, 2), "pred_boxes": torch.rand(3, 4, 10).transpose(1, 2)}], 3, 8, True) is None
+
+
+def test_launch_targets_refuses_what_it_cannot_launch():
+    """detr_amd._index_views.launch_targets on the CPU: inconsistent arguments raise, host tensors are
+    'not this path' (None) -- in neither case is the entry point called (its address here is a dummy)."""
+    from detr_amd.matcher import _index_views as iv
+
+    targets = [{"labels": torch.tensor([1, 0, 1]), "boxes": torch.rand(3, 4)},
+               {"labels": torch.tensor([0]), "boxes": torch.rand(1, 4)}]
+    sizes, total, max_t, pointers, tensors, versions, offsets, meta = iv.scan_targets(targets, -1)
+    outs = [{"pred_logits": torch.rand(2, 10, 2), "pred_boxes": torch.rand(2, 10, 4)}]
+    dummy = 0xDEAD0
+    assert iv.launch_targets(outs, 2, total, max_t, pointers, meta, dummy, dummy, dummy, 1 << 20, 0, 0) is None
+    with pytest.raises(ValueError):      # pointer table of another batch size
+        iv.launch_targets(outs, 3, total, max_t, pointers, meta, dummy, dummy, dummy, 1 << 20, 0, 0)
+    with pytest.raises(ValueError):      # no entry point
+        iv.launch_targets(outs, 2, total, max_t, pointers, meta, 0, dummy, dummy, 1 << 20, 0, 0)
