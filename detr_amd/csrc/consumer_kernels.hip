@@ -246,9 +246,7 @@ int launch_scatter(const DmIndexSet *sets, int S, int B, int M, const int32_t *t
         const size_t lds = (size_t)max_q * sizeof(int);
         if (lds > 160 * 1024) return DM_E_UNSUPPORTED;
         if (lds > 64 * 1024) {
-            rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                               "hipFuncSetAttribute(scatter_rows_kernel)");
+            rc = dm::allow_lds(reinterpret_cast<const void *>(kernel), lds, "hipFuncSetAttribute(scatter_rows_kernel)");
             if (rc != DM_OK) return rc;
         }
         hipLaunchKernelGGL(kernel, dim3(B, n), dim3(256), lds, st, arr, M, tgt_off, src, tgt,

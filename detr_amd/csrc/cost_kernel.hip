@@ -20,6 +20,8 @@
 // and the final sums use explicit fma -- within 1e-7 relative of the reference's
 // separately rounded operations, far inside the 1e-5 parity bar.
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 #include "cost_math.h"
 
@@ -484,6 +486,28 @@ int check_hip(hipError_t e, const char *what)
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
     return DM_E_LAUNCH;
 }
+
+// Kernels that may need more than 64 KB of dynamic LDS: the attribute is raised once per (function, device)
+// to the largest size asked for so far; the record of what has been set is shared by all host threads.
+int allow_lds(const void *fn, size_t bytes, const char *what)
+{
+    struct Entry { const void *fn; int dev; size_t bytes; };
+    static std::mutex mu;
+    static std::vector<Entry> set_on;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    Entry *mine = nullptr;
+    for (auto &e : set_on)
+        if (e.fn == fn && e.dev == dev) { mine = &e; break; }
+    if (mine && mine->bytes >= bytes) return DM_OK;
+    int rc = check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), what);
+    if (rc == DM_OK && dev >= 0) {
+        if (mine) mine->bytes = bytes;
+        else set_on.push_back(Entry{fn, dev, bytes});
+    }
+    return rc;
+}
 }  // namespace dm
 
 extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
@@ -508,9 +532,7 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     const TileFn tile_fn = tile_waves == 4 ? DM_TILE_FN(4) : DM_TILE_FN(8);
 #undef DM_TILE_FN
     if (tile && tile_lds > 64 * 1024) {
-        int rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_fn),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds),
-                               "hipFuncSetAttribute(cost_tile_kernel)");
+        int rc = dm::allow_lds(reinterpret_cast<const void *>(tile_fn), tile_lds, "hipFuncSetAttribute(cost_tile_kernel)");
         if (rc != DM_OK) return rc;
     }
 

@@ -111,6 +111,7 @@ __device__ __forceinline__ void raise_status(int32_t *status, int bits)
 
 struct FusedIn;
 int check_hip(hipError_t e, const char *what);
+int allow_lds(const void *fn, size_t bytes, const char *what);
 int lap_plan(const DmSet *sets, int S, int B, int max_T, unsigned char *needs_cost);
 bool lap_can_fuse(int C, int max_T);
 int lap_run(const DmSet *sets, int S, int B, const float *cost, const int32_t *tgt_off, const int32_t *order,

@@ -941,22 +941,6 @@ int ncol_class(int Q)
     return 0;
 }
 
-// Kernels that may need more than 64 KB of dynamic LDS get the attribute once per (function, device);
-// the record of where it has been set is shared by all host threads.
-int allow_big_lds(const void *fn, const char *what)
-{
-    static std::mutex mu;
-    static std::vector<std::pair<const void *, int>> set_on;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-    std::lock_guard<std::mutex> lock(mu);
-    for (const auto &e : set_on)
-        if (e.first == fn && e.second == dev) return DM_OK;
-    int rc = dm::check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024), what);
-    if (rc == DM_OK && dev >= 0) set_on.emplace_back(fn, dev);
-    return rc;
-}
-
 // Everything a launch of a register kernel needs besides its shape.
 struct LapArgs {
     int B;
@@ -986,7 +970,7 @@ int launch_wave(const DmSetArray &arr, int n, const LapArgs &a, int max_Q, int m
     if (fixed + want > budget) want = budget - fixed;
     want &= ~(size_t)15;
     if (fixed + want > 64 * 1024) {
-        int rc = allow_big_lds(reinterpret_cast<const void *>(&lap_wave_kernel<NCOL>), "hipFuncSetAttribute(lap_wave_kernel)");
+        int rc = dm::allow_lds(reinterpret_cast<const void *>(&lap_wave_kernel<NCOL>), 80 * 1024, "hipFuncSetAttribute(lap_wave_kernel)");
         if (rc != DM_OK) return rc;
     }
     hipLaunchKernelGGL(lap_wave_kernel<NCOL>, dim3((unsigned)n * a.B), dim3(64), fixed + want, a.st, arr, n, a.cost,
@@ -1047,7 +1031,7 @@ int launch_block(const DmSetArray &arr, int n, const LapArgs &a, int waves, int 
     auto kernel = fused ? (wide ? lap_block_kernel<NCOL, CAN_WIDE, true> : lap_block_kernel<NCOL, false, true>)
                         : (wide ? lap_block_kernel<NCOL, CAN_WIDE, false> : lap_block_kernel<NCOL, false, false>);
     if (fixed + want > 64 * 1024) {
-        int rc = allow_big_lds(reinterpret_cast<const void *>(kernel), "hipFuncSetAttribute(lap_block_kernel)");
+        int rc = dm::allow_lds(reinterpret_cast<const void *>(kernel), 80 * 1024, "hipFuncSetAttribute(lap_block_kernel)");
         if (rc != DM_OK) return rc;
     }
     const dm::FusedIn fin = fused ? *a.fin : dm::FusedIn{};
@@ -1267,8 +1251,7 @@ int lap_run(const DmSet *sets, int S, int B, const float *cost, const int32_t *t
             const size_t lds = (size_t)c_cap * 28 + (size_t)r_cap * 12;
             if (lds > 160 * 1024) return DM_E_UNSUPPORTED;
             if (lds > 64 * 1024) {
-                rc = dm::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&lap_generic_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                rc = dm::allow_lds(reinterpret_cast<const void *>(&lap_generic_kernel), lds,
                                    "hipFuncSetAttribute(lap_generic_kernel)");
                 if (rc != DM_OK) return rc;
             }
