@@ -129,6 +129,6 @@ def check(rc, what):
         msg += ": " + lib.dm_last_hip_error().decode()
     if rc == E_UNSUPPORTED:
         raise NotImplementedError(
-            f"{what}: {msg} (B <= 65535 images, S <= 4096 sets, C <= 611 classes (627 with the focal class cost), "
+            f"{what}: {msg} (B <= 65535 images, S <= 4096 sets, "
             "Q and T <= 4096 per problem; see include/detr_match.h)")
     raise RuntimeError(f"{what}: {msg}")

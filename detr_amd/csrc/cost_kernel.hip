@@ -436,6 +436,92 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     }
 }
 
+// C beyond what a 64-row logit tile in LDS can hold (about 600 classes): the same decomposition as the tile
+// kernel -- four wavefronts per tile of 64 queries, targets split four ways -- with the logits read from memory
+// where the tile kernel reads its LDS tile: sixteen lanes walk a row's consecutive words for the softmax
+// statistics (64-byte pieces), and the one logit a (query, target) pair needs is gathered by the query's lane.
+// MODE as for the tile kernel.
+template <int MODE>
+__global__ __launch_bounds__(256) void cost_wide_kernel(const DmSetArray sets, const int nsets, const int B, const int C,
+                                                        const int64_t *__restrict__ labels,
+                                                        const float *__restrict__ tboxes,
+                                                        const int32_t *__restrict__ tgt_off, const DmParams prm,
+                                                        float *__restrict__ cost, int32_t *status)
+{
+    constexpr int W = 4;
+    __shared__ TgtRec tg[TCHUNK];
+    __shared__ float part[128];           // softmax statistics of the tile's rows: maximum | -1 / sum
+
+    const int b = blockIdx.y;
+    const DmSet &set = sets.s[blockIdx.z];
+    const int Q = set.Q;
+    const int q0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = q0 + lane;
+    const bool active = q < Q;
+    const int t0 = tgt_off[b];
+    const int T = tgt_off[b + 1] - t0;
+    const size_t row = (size_t)b * Q + (active ? q : Q - 1);
+    const PredBox p = make_pred(reinterpret_cast<const float4 *>(set.boxes)[row]);
+    if (active && wave == 0 && !pred_valid(p)) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
+    if (T == 0) return;
+
+    const float *xr = set.logits + row * (size_t)C;
+    constexpr float LOG2E = 1.44269504088896f;
+    float ce_max = 0.0f, ce_scale = 1.0f;
+    if (MODE == 0) {
+        const int sub = lane & 15;
+        for (int g = 0; g < 16 / W; ++g) {
+            const int r = 4 * wave + 4 * W * g + (lane >> 4);
+            const float *xrow = set.logits + ((size_t)b * Q + min(q0 + r, Q - 1)) * (size_t)C;
+            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+            int c = sub;
+            for (; c + 48 < C; c += 64) {
+                m0 = vmax(m0, xrow[c]); m1 = vmax(m1, xrow[c + 16]); m2 = vmax(m2, xrow[c + 32]); m3 = vmax(m3, xrow[c + 48]);
+            }
+            for (; c < C; c += 16) m0 = vmax(m0, xrow[c]);
+            const float mx = row16_all<false>(vmax(vmax(m0, m1), vmax(m2, m3)));
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            c = sub;
+            for (; c + 48 < C; c += 64) {
+                s0 += __builtin_amdgcn_exp2f((xrow[c] - mx) * LOG2E);
+                s1 += __builtin_amdgcn_exp2f((xrow[c + 16] - mx) * LOG2E);
+                s2 += __builtin_amdgcn_exp2f((xrow[c + 32] - mx) * LOG2E);
+                s3 += __builtin_amdgcn_exp2f((xrow[c + 48] - mx) * LOG2E);
+            }
+            for (; c < C; c += 16) s0 += __builtin_amdgcn_exp2f((xrow[c] - mx) * LOG2E);
+            const float sum = row16_all<true>((s0 + s1) + (s2 + s3));
+            if (sub == 0) {
+                part[r] = mx;
+                part[64 + r] = -1.0f / sum;       // class cost = -softmax
+            }
+        }
+        __syncthreads();
+        ce_max = part[lane];
+        ce_scale = part[64 + lane];
+    }
+
+    const int qs = set.q_stride;
+    float *out = cost + set.cost_off + (size_t)t0 * qs;
+    for (int tc = 0; tc < T; tc += TCHUNK) {
+        const int nt = min(TCHUNK, T - tc);
+        if (tc > 0) __syncthreads();
+        stage_targets(tg, labels, tboxes, t0 + tc, nt, C, status);
+        __syncthreads();
+        if (active) {
+            for (int i = wave; i < nt; i += W) {
+                const TgtRec g = tg[i];
+                const float xl = xr[g.label];
+                float cls;
+                if (MODE == 0) cls = __builtin_amdgcn_exp2f((xl - ce_max) * LOG2E) * ce_scale;
+                else cls = focal_cost<MODE == 1>(xl, prm.focal_alpha, prm.focal_gamma);
+                out[(size_t)(tc + i) * qs + q] = pair_cost(p, g, prm.w_class * cls, prm.w_bbox, prm.w_giou);
+            }
+        }
+    }
+}
+
 // waves per workgroup: fewest padded lanes over the tiles of one image, larger blocks on ties
 int pick_waves(int Q, int max_waves)
 {
@@ -525,13 +611,14 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
     const int tile_waves = g_tile_waves == 8 ? 8 : 4;
     const size_t tile_lds = TCHUNK * sizeof(TgtRec) + (mode == 0 ? 64 * 2 * sizeof(float) : 0) +
                             (size_t)64 * C * sizeof(float);
-    if (tile && tile_lds > 160 * 1024) return DM_E_UNSUPPORTED;
+    // (160 KB is the CU's LDS; the tile kernel is used while a workgroup's share stays within it)
+    const bool wide = tile && tile_lds > 160 * 1024;
     typedef void (*TileFn)(const DmSetArray, const int, const int, const int, const int64_t *, const float *,
                            const int32_t *, const DmParams, float *, int32_t *, const int);
 #define DM_TILE_FN(WW) (mode == 0 ? cost_tile_kernel<WW, 0> : mode == 1 ? cost_tile_kernel<WW, 1> : cost_tile_kernel<WW, 2>)
     const TileFn tile_fn = tile_waves == 4 ? DM_TILE_FN(4) : DM_TILE_FN(8);
 #undef DM_TILE_FN
-    if (tile && tile_lds > 64 * 1024) {
+    if (tile && !wide && tile_lds > 64 * 1024) {
         int rc = dm::allow_lds(reinterpret_cast<const void *>(tile_fn), tile_lds, "hipFuncSetAttribute(cost_tile_kernel)");
         if (rc != DM_OK) return rc;
     }
@@ -550,7 +637,18 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
                 done[s] = true;
             }
             if (n == DM_MAX_SETS_PER_LAUNCH || (s == S && n > 0)) {
-                if (tile) {
+                if (wide) {
+                    const dim3 grid((unsigned)((Q + 63) / 64), (unsigned)B, (unsigned)n);
+                    if (mode == 0)
+                        hipLaunchKernelGGL(cost_wide_kernel<0>, grid, dim3(256), 0, st, arr, n, B, C, tgt_labels, tgt_boxes,
+                                           tgt_off, *params, cost, status);
+                    else if (mode == 1)
+                        hipLaunchKernelGGL(cost_wide_kernel<1>, grid, dim3(256), 0, st, arr, n, B, C, tgt_labels, tgt_boxes,
+                                           tgt_off, *params, cost, status);
+                    else
+                        hipLaunchKernelGGL(cost_wide_kernel<2>, grid, dim3(256), 0, st, arr, n, B, C, tgt_labels, tgt_boxes,
+                                           tgt_off, *params, cost, status);
+                } else if (tile) {
                     const int ntiles = (Q + 63) / 64;
                     hipLaunchKernelGGL(tile_fn, dim3((unsigned)ntiles, (unsigned)B, (unsigned)n), dim3(64 * tile_waves),
                                        tile_lds, st, arr, n, B, C, tgt_labels, tgt_boxes, tgt_off, *params, cost, status,

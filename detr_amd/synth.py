@@ -46,6 +46,11 @@ WORKLOADS = {
     # Co-DETR scale: 6 layers x 2 heads
     # cfg4 with the softmax class cost of the reference's 'ce' models: 91 classes + no-object = 92 logits
     "cfg4_ce": Workload("cfg4_ce", 256, [900] * 6, 92, 91, "ce", "heavy_tail", dict(cls_loss="ce", **_W), 4000),
+    # an LVIS-size class head (1203 classes): beyond what a 64-row logit tile in LDS holds
+    "wide_focal": Workload("wide_focal", 4, [300, 100], 1203, 1203, "focal", "poisson16", dict(cls_loss="focal", **_W), 6000),
+    "wide_ce": Workload("wide_ce", 4, [300, 100], 1204, 1203, "ce", "poisson16", dict(cls_loss="ce", **_W), 6100),
+    "wide_focal_g15": Workload("wide_focal_g15", 3, [130], 700, 700, "focal", "heavy_tail",
+                               dict(cls_loss="focal", **dict(_W, focal_gamma=1.5)), 6200),
     "cfg5": Workload("cfg5", 1024, [600] * 12, 2, 2, "focal", "poisson16", dict(cls_loss="focal", **_W), 5000),
 }
 

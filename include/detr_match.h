@@ -107,8 +107,9 @@ int dm_pack_targets(const uint64_t *pointers, const int32_t *meta, int B, int64_
  *   status   device int32[1], OR-ed with DM_ST_LABEL_RANGE / DM_ST_DEGENERATE_BOX
  * Prediction boxes of every image are validated, also of images without targets,
  * as the reference's batch-wide assert does.
- * Limits (DM_E_UNSUPPORTED beyond): B <= 65535 images, S <= 4096 sets, and for C > 4 a tile of 64 logit rows
- * must fit in LDS: 64 * C * 4 bytes + 3 KB (+ 4 KB with cls_mode 0) <= 160 KB, i.e. C <= 627 (611).
+ * Limits (DM_E_UNSUPPORTED beyond): B <= 65535 images, S <= 4096 sets.  Any C: while a tile of 64 logit rows
+ * fits in LDS (64 * C * 4 bytes + 3.5 KB <= 160 KB, C <= 626) the logits are streamed through LDS once; beyond
+ * that a slower kernel reads them from memory (softmax statistics in 64-byte pieces, one gathered logit per pair).
  */
 int dm_cost_f32(const DmSet *sets, int S, int B, int C,
                 const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,

@@ -244,6 +244,14 @@ def test_workload_cfg3_wide_first_stage():
     assert exact >= 0.99 * total
 
 
+@pytest.mark.parametrize("name", ["wide_focal", "wide_ce", "wide_focal_g15"])
+def test_class_counts_beyond_the_lds_tile(name):
+    """More classes than a 64-row logit tile in LDS can hold (C > ~600, e.g. LVIS's 1203): the cost kernel that
+    reads the logits from memory; same bars as every other shape."""
+    exact, total = _check_workload(name)
+    assert exact >= 0.99 * total
+
+
 def test_workload_cfg4_reduced_batch():
     exact, total = _check_workload("cfg4", batch=24)
     assert exact >= 0.99 * total
