@@ -16,6 +16,7 @@ from itertools import accumulate
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import ctypes
+import functools
 
 import numpy as np
 import torch
@@ -550,6 +551,19 @@ class HungarianMatcher(torch.nn.Module):
         _lib.check(rc, "dm_match_flat_f32" if want_cost else "dm_match_fused_f32")
         return out, queries, cost, strides
 
+    @staticmethod
+    def _by_class_count(outputs_list):
+        """None when all output sets have the same number of logits per query (one pass handles them);
+        otherwise the positions of the sets of each class count -- heads with different class counts, e.g. a
+        class-agnostic first stage beside the decoder layers, take one pass per class count on the same targets."""
+        first = outputs_list[0]["pred_logits"].shape[-1]
+        if all(o["pred_logits"].shape[-1] == first for o in outputs_list):
+            return None
+        groups = {}
+        for i, o in enumerate(outputs_list):
+            groups.setdefault(int(o["pred_logits"].shape[-1]), []).append(i)
+        return list(groups.values())
+
     @torch.no_grad()
     def match_many(self, outputs_list: Sequence[Dict[str, torch.Tensor]],
                    targets: Union[PackedTargets, Sequence[Dict[str, torch.Tensor]]],
@@ -567,6 +581,20 @@ class HungarianMatcher(torch.nn.Module):
         S = len(outputs_list)
         if S == 0:
             return []
+        groups = self._by_class_count(outputs_list)
+        if groups is not None:
+            result, costs, statuses = [None] * S, [None] * S, []
+            for members in groups:
+                part = self.match_many([outputs_list[i] for i in members], targets, device_indices, return_cost)
+                if self.last_status is not None:
+                    statuses.append(self.last_status)
+                for k, i in enumerate(members):
+                    result[i] = part[0][k] if return_cost else part[k]
+                    if return_cost:
+                        costs[i] = part[1][k]
+            if statuses:
+                self.last_status = functools.reduce(torch.bitwise_or, statuses)
+            return (result, costs) if return_cost else result
         device = outputs_list[0]["pred_logits"].device
         packed = self._packed_for(targets, device)
         M, sizes = packed.total, packed.sizes
@@ -653,6 +681,18 @@ class HungarianMatcher(torch.nn.Module):
         S = len(outputs_list)
         if S == 0:
             return []
+        groups = self._by_class_count(outputs_list)
+        if groups is not None:
+            result, statuses = [None] * S, []
+            for members in groups:
+                part = self.match_flat([outputs_list[i] for i in members], targets)
+                statuses.append(self.last_status)
+                for k, i in enumerate(members):
+                    result[i] = part[k] if part else None
+            if all(r is None for r in result):
+                return []
+            self.last_status = functools.reduce(torch.bitwise_or, [st for st in statuses if st is not None])
+            return result
         device = outputs_list[0]["pred_logits"].device
         packed = self._packed_for(targets, device)
         if packed.batch == 0:

@@ -208,3 +208,41 @@ def test_one_call_launch_equals_the_general_path():
         _assert_identical(c, detr_amd.HungarianMatcher(**wl5.matcher_kwargs).match_many(sets5[:2], targets5))
     finally:
         mm._index_views = helper
+
+
+def test_output_sets_with_different_class_counts():
+    """Heads with different class counts in one call (a 3-logit and a 7-logit head here): one pass per class
+    count, results in the caller's order, equal to calling the matcher once per set as the reference does;
+    the status of a device-resident call is the OR over the passes."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg1", device="cuda", batch=5)        # 3 logits, labels < 2
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wide = synth.make_output_set(5, 130, 7, g, "cuda")
+    mixed = [sets[0], wide, sets[1]]
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    together = matcher.match_many(mixed, targets)
+    one_by_one = [matcher(o, targets) for o in mixed]
+    _assert_identical(together, one_by_one)
+    res, costs = matcher.match_many(mixed, targets, return_cost=True)
+    _assert_identical(res, one_by_one)
+    assert [tuple(c.shape) for c in costs] == [(sum(len(t["labels"]) for t in targets), o["pred_logits"].shape[1]) for o in mixed]
+    flats = matcher.match_flat(mixed, targets)
+    matcher.check_status()
+    for f, ref in zip(flats, one_by_one):
+        assert torch.equal(f.src_idx.cpu(), torch.cat([i for i, _ in ref]))
+        assert torch.equal(f.tgt_idx.cpu(), torch.cat([j for _, j in ref]))
+    # a label that only the 3-logit heads reject
+    bad = [dict(t) for t in targets]
+    bad[2] = {"labels": torch.full_like(targets[2]["labels"], 5), "boxes": targets[2]["boxes"]}
+    assert len(bad[2]["labels"]) > 0
+    matcher.match_many([wide], bad)                      # fine for the 7-logit head alone
+    with pytest.raises(IndexError):
+        matcher.match_many(mixed, bad)
+    matcher.match_many(mixed, bad, device_indices=True)
+    with pytest.raises(IndexError):
+        matcher.check_status()
+    matcher.match_flat([wide, sets[0]], bad)
+    with pytest.raises(IndexError):
+        matcher.check_status()
