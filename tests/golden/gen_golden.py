@@ -122,6 +122,11 @@ def build_cases():
     c["logits"] *= 4.0
     cases["focal_c2_saturated"] = c
 
+    # class heads beyond what a 64-row logit tile in LDS holds (an LVIS-size head): the kernel that reads
+    # the logits from memory
+    cases["focal_c1203_q70"] = regular_case(58, "focal", 1203, 1203, 3, 70, [11, 0, 25], (2.0, 5.0, 2.0))
+    cases["ce_c1204_q70"] = regular_case(59, "ce", 1204, 1203, 3, 70, [11, 0, 25], (1.0, 5.0, 2.0))
+
     # error cases: the reference must raise
     c = regular_case(61, "ce", 3, 2, 2, 30, [4, 3], (2.0, 5.0, 2.0))
     c["logits"][1, 7, 1] = float("nan")
