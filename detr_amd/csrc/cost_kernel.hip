@@ -318,63 +318,79 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     if (MODE == 0) {
         // Softmax statistics (row maximum, -1 / sum of exp(x - max): the reference's own formulation) of the 64 rows.
         // Sixteen lanes share a row and walk its columns side by side (consecutive words: no index arithmetic per
-        // element), four rows per wavefront and group, the groups interleaved; the sixteen partial results meet through four DPP steps in a
-        // fixed order, so the result depends neither on the number of wavefronts nor on which of them took the row.
-        constexpr int NG = 16 / W;                  // row groups per wavefront: rows 4 * wave + 4 * W * g + (lane >> 4)
+        // element), four rows per wavefront instruction, the row groups of a wavefront interleaved; the sixteen partial
+        // results meet through four DPP steps in a fixed order.
+        // Which rows meet in a wavefront instruction: the two rows of a 32-lane half (the unit in which LDS banks
+        // conflict) sit k rows apart with k * C = 16 (mod 32), so that their 16-word windows fall on disjoint banks
+        // (k = 16 >> number of trailing zero bits of C; none exists when C is a multiple of 32).
+        constexpr int NG = 16 / W;                  // row groups per wavefront
+        constexpr int GBITS = NG == 4 ? 2 : 1;
+        typedef float f2 __attribute__((ext_vector_type(2)));
         const int sub = lane & 15;
-        const int r = 4 * wave + (lane >> 4);       // rows >= nq read tile space nobody wrote: results unused
-        const float *xrow = tile + r * C + sub;
-        const int gstep = 4 * W * C;
-        float mx[NG], sum[NG];
+        const int kb = 4 - min(__builtin_ctz(C), 4);
+        const int slot0 = (lane >> 4) & 1, slot1 = lane >> 5;
+        int rg[NG];
+        const float *pg[NG];
+        float mx[NG];
+        f2 sum[NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { mx[g] = -INFINITY; sum[g] = 0.0f; }
+        for (int g = 0; g < NG; ++g) {
+            const int n = slot1 | (g << 1) | (wave << (1 + GBITS));        // the other five bits of the row number
+            rg[g] = ((n >> kb) << (kb + 1)) | (slot0 << kb) | (n & ((1 << kb) - 1));
+            pg[g] = tile + rg[g] * C + sub;      // rows >= nq read tile space nobody wrote: results unused
+            mx[g] = -INFINITY;
+            sum[g] = f2{0.0f, 0.0f};
+        }
         const int nfull = C >> 4;                   // chunks of 16 columns that every lane of the group has
         const bool tail = sub < (C & 15);
         {
-            const float *p = xrow;
-            int k = nfull;
-            for (; k >= 4; k -= 4, p += 64) {
+            int k = nfull, o = 0;
+            for (; k >= 4; k -= 4, o += 64) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], p[g * gstep + 16 * j]);
+                    for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], pg[g][o + 16 * j]);
             }
-            for (; k > 0; --k, p += 16) {
+            for (; k > 0; --k, o += 16) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], p[g * gstep]);
+                for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], pg[g][o]);
             }
             if (tail) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], p[g * gstep]);
+                for (int g = 0; g < NG; ++g) mx[g] = vmax(mx[g], pg[g][o]);
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) mx[g] = row16_all<false>(mx[g]);
         {
-            auto term = [&](int g, float x) { sum[g] += __builtin_amdgcn_exp2f((x - mx[g]) * LOG2E); };
-            const float *p = xrow;
-            int k = nfull;
-            for (; k >= 4; k -= 4, p += 64) {
+            // two logits per packed subtraction / multiplication / addition; the exponentials stay single
+            auto term2 = [&](int g, float x0, float x1) {
+                const f2 t = (f2{x0, x1} - f2{mx[g], mx[g]}) * f2{LOG2E, LOG2E};
+                sum[g] += f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            };
+            auto term = [&](int g, float x) { sum[g].x += __builtin_amdgcn_exp2f((x - mx[g]) * LOG2E); };
+            int k = nfull, o = 0;
+            for (; k >= 4; k -= 4, o += 64) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; j += 2)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) term(g, p[g * gstep + 16 * j]);
+                    for (int g = 0; g < NG; ++g) term2(g, pg[g][o + 16 * j], pg[g][o + 16 * j + 16]);
             }
-            for (; k > 0; --k, p += 16) {
+            for (; k > 0; --k, o += 16) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) term(g, p[g * gstep]);
+                for (int g = 0; g < NG; ++g) term(g, pg[g][o]);
             }
             if (tail) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) term(g, p[g * gstep]);
+                for (int g = 0; g < NG; ++g) term(g, pg[g][o]);
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            sum[g] = row16_all<true>(sum[g]);
+            const float total = row16_all<true>(sum[g].x + sum[g].y);
             if (sub == 0) {
-                part[r + 4 * W * g] = mx[g];
-                part[64 + r + 4 * W * g] = -1.0f / sum[g];       // class cost = -softmax
+                part[rg[g]] = mx[g];
+                part[64 + rg[g]] = -1.0f / total;       // class cost = -softmax
             }
         }
         __syncthreads();
