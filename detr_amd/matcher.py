@@ -409,9 +409,11 @@ class HungarianMatcher(torch.nn.Module):
         cached = self._packed
         if cached is not None and cached.device == device and cached.same_targets(targets):
             return cached
-        self._packed = None          # (a failed packing must not leave a stale entry)
+        # (plain dictionary stores: nn.Module.__setattr__ costs a microsecond per assignment)
+        state = self.__dict__
+        state["_packed"] = None          # (a failed packing must not leave a stale entry)
         packed = PackedTargets(targets, device, defer=True)
-        self._packed = packed
+        state["_packed"] = packed
         return packed
 
     def _workspace(self, device, n_out: int, n_cost: int):
@@ -457,8 +459,9 @@ class HungarianMatcher(torch.nn.Module):
         if rc == _lib.NEED_BUFFERS:     # the step has to pack its targets: not this path's business for a while
             self._skip_fast = 64
             return None
-        _lib.check(rc, "dm_match_targets_f32")
-        self.last_status = None
+        if rc:
+            _lib.check(rc, "dm_match_targets_f32")
+        self.__dict__["last_status"] = None
         return host, queries
 
     def _launch(self, outputs_list, packed: PackedTargets, flat: bool = False, own_buffers: bool = False,
@@ -564,6 +567,23 @@ class HungarianMatcher(torch.nn.Module):
             groups.setdefault(int(o["pred_logits"].shape[-1]), []).append(i)
         return list(groups.values())
 
+    def _match_groups(self, groups, outputs_list, targets, device_indices, return_cost):
+        """match_many for output sets of several class counts: one pass per class count, results in the caller's
+        order; the status of a device-resident call is the OR over the passes."""
+        S = len(outputs_list)
+        result, costs, statuses = [None] * S, [None] * S, []
+        for members in groups:
+            part = self.match_many([outputs_list[i] for i in members], targets, device_indices, return_cost)
+            if self.last_status is not None:
+                statuses.append(self.last_status)
+            for k, i in enumerate(members):
+                result[i] = part[0][k] if return_cost else part[k]
+                if return_cost:
+                    costs[i] = part[1][k]
+        if statuses:
+            self.last_status = functools.reduce(torch.bitwise_or, statuses)
+        return (result, costs) if return_cost else result
+
     @torch.no_grad()
     def match_many(self, outputs_list: Sequence[Dict[str, torch.Tensor]],
                    targets: Union[PackedTargets, Sequence[Dict[str, torch.Tensor]]],
@@ -581,20 +601,6 @@ class HungarianMatcher(torch.nn.Module):
         S = len(outputs_list)
         if S == 0:
             return []
-        groups = self._by_class_count(outputs_list)
-        if groups is not None:
-            result, costs, statuses = [None] * S, [None] * S, []
-            for members in groups:
-                part = self.match_many([outputs_list[i] for i in members], targets, device_indices, return_cost)
-                if self.last_status is not None:
-                    statuses.append(self.last_status)
-                for k, i in enumerate(members):
-                    result[i] = part[0][k] if return_cost else part[k]
-                    if return_cost:
-                        costs[i] = part[1][k]
-            if statuses:
-                self.last_status = functools.reduce(torch.bitwise_or, statuses)
-            return (result, costs) if return_cost else result
         device = outputs_list[0]["pred_logits"].device
         packed = self._packed_for(targets, device)
         M, sizes = packed.total, packed.sizes
@@ -602,6 +608,9 @@ class HungarianMatcher(torch.nn.Module):
             return [[] for _ in range(S)]
 
         if device_indices:
+            groups = self._by_class_count(outputs_list)
+            if groups is not None:
+                return self._match_groups(groups, outputs_list, targets, device_indices, return_cost)
             out, queries, cost, strides = self._launch(outputs_list, packed, want_cost=return_cost)
             result = self._split(out, S, M, sizes, queries, packed.offsets_list)
         else:
@@ -609,6 +618,11 @@ class HungarianMatcher(torch.nn.Module):
             n = 2 * S * M + 1
             direct = own and self.indices_to_host and device.index in (None, torch.cuda.current_device())
             fast = self._launch_to_host(outputs_list, packed, device) if direct else None
+            if fast is None:
+                # (the one-call path has checked the class counts itself; anything else is checked here)
+                groups = self._by_class_count(outputs_list)
+                if groups is not None:
+                    return self._match_groups(groups, outputs_list, targets, device_indices, return_cost)
             if fast is not None:
                 host, queries = fast
                 status_word = ctypes.c_int64.from_address(host.data_ptr())
