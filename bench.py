@@ -373,6 +373,9 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         fused = wl.n_logits <= 4 and max(sizes) <= 256 and all(q > max(sizes) for q in wl.set_queries)
+        # logits + boxes of every prediction, labels + boxes of every target per set, two int64 indices per match
+        step_bytes = sum(B * q * (wl.n_logits * 4 + 16) + sum(sizes) * 24 + 16 * sum(min(q, t) for t in sizes)
+                         for q in wl.set_queries)
         # The cost kernel on this run's inputs.  When the step runs as ONE kernel (C <= 4: every assignment
         # workgroup computes its own cost block in LDS, no cost matrix in HBM) the cost kernel is not part of
         # the headline step any more; it is still the kernel the cost-kernel HBM figure of the metric is
@@ -409,7 +412,14 @@ def main():
                              "assignment_kernel_ms_per_step": lap_ms_avg,
                              "assignment_kernel_traffic_bytes": (measured_traffic("lap_block_kernel", wl.name)
                                                                  if fused and B == wl.batch else None),
-                             "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3)},
+                             "problems_per_s": len(wl.set_queries) * B / (lap_ms_avg * 1e-3),
+                             # what this kernel has to move when it computes its own cost blocks: predictions and
+                             # targets in, indices out -- a latency-bound kernel, its time is the dependent chain
+                             # of the heaviest problem of the step, not its traffic
+                             "algorithmic_bytes": step_bytes if fused else None,
+                             "achieved_gbs": (step_bytes / (lap_ms_avg * 1e-3) / 1e9) if fused and lap_ms_avg else None,
+                             "frac_of_hbm_peak": (step_bytes / (lap_ms_avg * 1e-3) / 1e9 / 8000.0) if fused and lap_ms_avg else None,
+                             "bound": "latency (one workgroup per problem; the step takes as long as its heaviest problem)"},
         }
         if world == 1:
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
