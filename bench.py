@@ -406,7 +406,8 @@ def main():
             "step_kernels": {"what": "HIP events on the launch stream around the kernels of every step, in a pass of "
                                      "its own (dm_profile_*)",
                              "one_kernel_per_step": fused,
-                             "cost_kernel_ms_per_step": cost_ms_avg,
+                             # (with one kernel per step there is no cost kernel between the first two events)
+                             "cost_kernel_ms_per_step": None if fused else cost_ms_avg,
                              "assignment_kernel": ("lap_block_kernel<FUSED>: cost block computed in LDS + assignment"
                                                    if fused else "lap_block_kernel / lap_wave_kernel"),
                              "assignment_kernel_ms_per_step": lap_ms_avg,
