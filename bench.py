@@ -306,12 +306,21 @@ def main():
     fresh = [[{k: v[:] for k, v in t.items()} for t in targets] for _ in range(4)]
     turn = [0]
 
+    # (a gloo rehearsal reduces host tensors: gloo's path for device tensors stages them through pinned memory of its
+    # own and stalls for hundreds of milliseconds at random when two ranks share one GPU)
+    reduce_on = device if args.backend == "nccl" else "cpu"
+
+    pending = [None]
+
+    def normaliser():
+        # the step's one collective, issued while the matching kernels run, on a stream of its own
+        pending[0] = start_num_boxes_all_reduce(counts, reduce_on)
+
     def step():
-        pending = start_num_boxes_all_reduce(counts, device) if world > 1 else None   # asynchronous
         turn[0] = (turn[0] + 1) & 3
-        indices = matcher.match_many(sets, fresh[turn[0]])
-        if pending is not None:
-            pending.result()        # the stream waits for the collective here, after the kernels were enqueued
+        indices = matcher.match_many(sets, fresh[turn[0]], while_waiting=normaliser if world > 1 else None)
+        if world > 1:
+            pending[0].result()     # where the loss needs the value: the stream (not the host) waits for the collective
         return indices
 
     def fence():

@@ -567,13 +567,15 @@ class HungarianMatcher(torch.nn.Module):
             groups.setdefault(int(o["pred_logits"].shape[-1]), []).append(i)
         return list(groups.values())
 
-    def _match_groups(self, groups, outputs_list, targets, device_indices, return_cost):
+    def _match_groups(self, groups, outputs_list, targets, device_indices, return_cost, while_waiting=None):
         """match_many for output sets of several class counts: one pass per class count, results in the caller's
         order; the status of a device-resident call is the OR over the passes."""
         S = len(outputs_list)
         result, costs, statuses = [None] * S, [None] * S, []
         for members in groups:
-            part = self.match_many([outputs_list[i] for i in members], targets, device_indices, return_cost)
+            part = self.match_many([outputs_list[i] for i in members], targets, device_indices, return_cost,
+                                   while_waiting)
+            while_waiting = None        # (once per call)
             if self.last_status is not None:
                 statuses.append(self.last_status)
             for k, i in enumerate(members):
@@ -587,7 +589,7 @@ class HungarianMatcher(torch.nn.Module):
     @torch.no_grad()
     def match_many(self, outputs_list: Sequence[Dict[str, torch.Tensor]],
                    targets: Union[PackedTargets, Sequence[Dict[str, torch.Tensor]]],
-                   device_indices: bool = False, return_cost: bool = False):
+                   device_indices: bool = False, return_cost: bool = False, while_waiting=None):
         """Match S output sets against the same targets.
 
         Returns a list (per set) of lists (per image) of ``(src, tgt)`` int64 tensors --
@@ -595,6 +597,10 @@ class HungarianMatcher(torch.nn.Module):
         ``device_indices=True`` (no host synchronisation; input errors are then only
         raised by ``check_status()``).  With ``return_cost=True`` also returns, per set,
         the ``[M, Q]`` device cost tensor (rows = packed targets).
+
+        ``while_waiting`` (CPU tuples only): a callable run once after the kernels have been enqueued and before
+        the host waits for them -- host work of the step that does not need the indices (issuing the collective
+        of the loss normalisation, for instance) then costs no time of its own.
 
         One matcher object serves one host thread at a time (it keeps device buffers between calls).
         """
@@ -622,7 +628,7 @@ class HungarianMatcher(torch.nn.Module):
                 # (the one-call path has checked the class counts itself; anything else is checked here)
                 groups = self._by_class_count(outputs_list)
                 if groups is not None:
-                    return self._match_groups(groups, outputs_list, targets, device_indices, return_cost)
+                    return self._match_groups(groups, outputs_list, targets, device_indices, return_cost, while_waiting)
             if fast is not None:
                 host, queries = fast
                 status_word = ctypes.c_int64.from_address(host.data_ptr())
@@ -641,6 +647,8 @@ class HungarianMatcher(torch.nn.Module):
                 host.copy_(out[:n], non_blocking=True)
                 done = self._done_event(device)
                 done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
+            if while_waiting is not None:
+                while_waiting()
             # the per-image views depend on shapes only: build them while the GPU is working
             if own:
                 result, status_at = self._split(host[1:], S, M, sizes, queries, packed.offsets_list), 0

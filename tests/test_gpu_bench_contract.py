@@ -80,3 +80,46 @@ def test_bench_two_ranks_over_rccl():
         pytest.skip("needs two GPUs")
     rec = _bench("--gpus", "2")
     assert rec["n_gpus"] == 2 and rec["value"] > 0
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[2]
+torch.cuda.set_device(0); dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+import detr_amd
+from detr_amd import synth
+from detr_amd.dist import matched_box_counts, start_num_boxes_all_reduce
+wl, sets, targets = synth.make_workload("cfg2", device=dev, batch=8)
+counts = matched_box_counts([len(t["labels"]) for t in targets], wl.set_queries) + [0]
+m = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+plain = m.match_many(sets, targets)
+pending = []
+for _ in range(12):      # more steps than the helper's rings of staging buffers and events hold
+    hooked = m.match_many(sets, [dict(t) for t in targets],
+                          while_waiting=lambda: pending.append(start_num_boxes_all_reduce(counts, dev, _always_reduce=True)))
+    got = pending[-1].result()
+    assert got.device == dev and got.tolist() == [float(max(c, 1)) for c in counts], got
+    for a, b in zip(plain, hooked):
+        for (a0, a1), (b0, b1) in zip(a, b):
+            assert torch.equal(a0, b0) and torch.equal(a1, b1)
+assert len(pending) == 12
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_collective_beside_the_kernels_over_rccl_one_rank():
+    """The step's collective issued from match_many's `while_waiting` hook, on its own stream, through RCCL (a group of
+    one rank: the box has one GPU): right values on the caller's stream, indices unchanged."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT, str(port)], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
