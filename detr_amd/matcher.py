@@ -28,7 +28,8 @@ Indices = List[Tuple[torch.Tensor, torch.Tensor]]
 
 _split_with_sizes = torch.ops.aten.unsafe_split_with_sizes.default
 _TARGETS_ENTRY = ctypes.cast(lib.dm_match_targets_f32, ctypes.c_void_p).value
-_raw_stream = torch._C._cuda_getCurrentRawStream       # (device index) -> the current stream's handle, no Stream object
+# (device index) -> the current stream's handle, without building a Stream object where torch offers that
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda index: torch.cuda.current_stream(index).cuda_stream)
 
 try:        # bulk creation of the per-image index views (csrc/index_views.cpp, built by build_ext.py)
     from . import _index_views
