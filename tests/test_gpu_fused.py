@@ -246,3 +246,37 @@ def test_output_sets_with_different_class_counts():
     matcher.match_flat([wide, sets[0]], bad)
     with pytest.raises(IndexError):
         matcher.check_status()
+
+
+def test_while_waiting_runs_once_per_call_on_every_path():
+    """`match_many(..., while_waiting=fn)`: fn runs exactly once, after the kernels have been enqueued, whichever way the
+    call takes -- the one-call launch, the device buffer + copy, the operators, several class counts -- and not at all
+    for a call that returns nothing to wait for; the indices are unaffected."""
+    import detr_amd
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload("cfg1", device="cuda", batch=4)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    other = synth.make_output_set(4, 90, 5, g, "cuda")
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    plain = matcher.match_many(sets[:2], targets)
+    calls = []
+
+    def hook():
+        calls.append(torch.cuda.current_stream().query())        # (any host work; the kernel may still be running)
+
+    assert matcher.match_many(sets[:2], targets, while_waiting=hook) is not None and len(calls) == 1
+    matcher.indices_to_host = False
+    _assert_identical(plain, matcher.match_many(sets[:2], targets, while_waiting=hook))
+    assert len(calls) == 2
+    matcher.indices_to_host, matcher.through_ops = True, True
+    _assert_identical(plain, matcher.match_many(sets[:2], targets, while_waiting=hook))
+    assert len(calls) == 3
+    matcher.through_ops = False
+    mixed = matcher.match_many([sets[0], other, sets[1]], targets, while_waiting=hook)
+    assert len(calls) == 4
+    _assert_identical([mixed[0], mixed[2]], plain)
+    res, _ = matcher.match_many(sets[:2], targets, return_cost=True, while_waiting=hook)
+    assert len(calls) == 5
+    _assert_identical(res, plain)
+    assert matcher.match_many([], targets, while_waiting=hook) == [] and len(calls) == 5
