@@ -116,11 +116,17 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
     for (int i = 0; i < QPT; ++i) small_class_costs(x[i], C, prm, wc[i]);
 
     // (opaque from here on: keeps the selection among the finished class costs from being rewritten
-    // as cost_class * (selection among the class costs), one more multiplication per pair)
+    // as cost_class * (selection among the class costs), one more multiplication per pair.  Held as one
+    // vector value per query, not as an array: the compiler turns a selection among three or four array
+    // elements into an indexed read of a per-thread table in LDS, whose addressing reads the workgroup size
+    // from the dispatch packet in host memory -- 14 us per launch.)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 wv[QPT];
 #pragma unroll
-    for (int i = 0; i < QPT; ++i)
-#pragma unroll
-        for (int c = 0; c < C; ++c) asm("" : "+v"(wc[i][c]));
+    for (int i = 0; i < QPT; ++i) {
+        wv[i] = f4{wc[i][0], wc[i][1], wc[i][2], wc[i][3]};
+        asm("" : "+v"(wv[i]));
+    }
 
     const int qs = set.q_stride;
     // wave-uniform row pointer (scalar registers) + the thread's query as a 32-bit offset
@@ -148,9 +154,10 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
                 vecq r;
 #pragma unroll
                 for (int k = 0; k < QPT; ++k) {
-                    float wcls = wc[k][0];
-#pragma unroll
-                    for (int c = 1; c < C; ++c) wcls = (l == c) ? wc[k][c] : wcls;
+                    float wcls = wv[k].x;
+                    if (C > 1) wcls = (l == 1) ? wv[k].y : wcls;
+                    if (C > 2) wcls = (l == 2) ? wv[k].z : wcls;
+                    if (C > 3) wcls = (l == 3) ? wv[k].w : wcls;
 #if DM_SMALL_ABL != 2
                     r[k] = pair_cost(p[k], g, wcls, prm.w_bbox, prm.w_giou);
 #endif
