@@ -523,6 +523,8 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_c1 = 0;
     int st_iters = 0;
+    __shared__ unsigned long long st_arr[16];      // arrival time of every wavefront at the step's barrier
+    unsigned long long st_spread = 0, st_release = 0, st_late[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0;
 #endif
 
@@ -671,8 +673,22 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 if (__builtin_amdgcn_inverse_ballot_w64(at & (0ull - at)))      // its lowest lane
                     rec[par * 16 + wave] = make_uint4(hi, lo, key, (unsigned)cj | ((unsigned)(cr + 1) << 16));
                 DM_STAMP(2)
+#ifdef DM_LAP_STAMPS
+                if (lane == 0) st_arr[wave] = st_t;
+#endif
                 __syncthreads();
                 DM_STAMP(3)
+#ifdef DM_LAP_STAMPS
+                if (tid == 0) {
+                    unsigned long long lo_ = ~0ull, hi_ = 0;
+                    for (int w_ = 0; w_ < W; ++w_) { lo_ = st_arr[w_] < lo_ ? st_arr[w_] : lo_; hi_ = st_arr[w_] > hi_ ? st_arr[w_] : hi_; }
+                    for (int w_ = 0; w_ < W; ++w_) st_late[w_] += st_arr[w_] - lo_;
+                    st_spread += hi_ - lo_;
+                    st_release += st_t - hi_;
+                }
+                __syncthreads();
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
+#endif
                 // every wave picks the workgroup's candidate from the W records
                 const uint4 x = rec[par * 16 + (lane & 15)];
                 const unsigned long long win = narrow_to_minimum<true>((1ull << W) - 1ull, x.x, x.y, x.z);
@@ -790,6 +806,10 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         unsigned long long *rec2 = reinterpret_cast<unsigned long long *>(status + 16) + (size_t)blockIdx.x * 12;
         rec2[0] = st_c1 - st_c0; rec2[1] = c2 - st_c1; rec2[2] = r2 - st_r0; rec2[3] = st_iters; rec2[4] = nr; rec2[5] = c2 - st_c0;
         for (int q = 0; q < 5; ++q) rec2[6 + q] = st_seg[q];
+        rec2[11] = st_spread;
+        unsigned long long *ext = reinterpret_cast<unsigned long long *>(status + 16) + (size_t)gridDim.x * 12 + (size_t)blockIdx.x * 18;
+        ext[0] = st_release; ext[1] = W;
+        for (int w_ = 0; w_ < 16; ++w_) ext[2 + w_] = st_late[w_];
     }
 #endif
     if (wave == 0) {

@@ -35,7 +35,7 @@ for s, o in enumerate(sets):
 cost = torch.empty(off, dtype=torch.float32, device=dev)
 out = torch.zeros(2 * S * M, dtype=torch.int64, device=dev)
 P = S * B
-status = torch.zeros(16 + P * 24, dtype=torch.int32, device=dev)
+status = torch.zeros(16 + P * 24 + P * 36, dtype=torch.int32, device=dev)
 prm = detr_amd.HungarianMatcher(**wl.matcher_kwargs)._params()
 vp = ctypes.c_void_p
 lib.dm_match_f32.argtypes = [ctypes.POINTER(DmSet), ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int,
@@ -46,7 +46,10 @@ for _ in range(3):
                           out.data_ptr() + 8 * S * M, status.data_ptr(), None)
     assert rc == 0
 torch.cuda.synchronize()
-rec = status[16:].cpu().numpy().view(np.uint64).reshape(P, 12).astype(np.float64)
+raw = status[16:].cpu().numpy().view(np.uint64)
+rec = raw[:P * 12].reshape(P, 12).astype(np.float64)
+ext = raw[P * 12:P * 30].reshape(P, 18).astype(np.float64)
+ext = ext[rec[:, 4] > 0]
 rec = rec[rec[:, 4] > 0]
 clk = rec[:, 5] / (rec[:, 2] * 10e-9) / 1e9   # s_memrealtime ticks at 100 MHz
 print("problems", len(rec), "clock GHz median %.2f" % np.median(clk))
@@ -60,3 +63,10 @@ print("least squares: cycles = %.0f * steps + %.0f * rows + %.0f" % tuple(coef))
 seg = rec[:, 6:11] / rec[:, 3:4]
 print("per-step segment cycles (median): seg0 %.0f | seg1 %.0f | seg2 %.0f | seg3 %.0f | seg4 %.0f" % tuple(np.median(seg, 0)))
 print("sum of segments per step %.0f ; row-end etc per row %.0f" % (np.median(seg.sum(1)), np.median((rec[:, 1] - rec[:, 6:11].sum(1)) / rec[:, 4])))
+if ext[:, 1].max() > 0:      # the workgroup kernel: arrival spread of its wavefronts at the step's barrier
+    steps = rec[:, 3:4]
+    print("per step (median over problems): arrival spread of the wavefronts %.0f cycles, last arrival -> wave 0 released %.0f" %
+          (np.median(rec[:, 11] / rec[:, 3]), np.median(ext[:, 0] / rec[:, 3])))
+    W = int(ext[:, 1].max())
+    late = np.median(ext[:, 2:2 + W] / steps, 0)
+    print("mean lateness per wavefront behind the first arrival:", " ".join("%.0f" % x for x in late))
