@@ -114,7 +114,7 @@ lib = _load()
 
 
 #: launch-shape knobs of dm_debug_set_knob (testing / tuning aid; 0 = automatic)
-KNOBS = {"lap_kernel": 0, "lap_max_waves": 1, "cost_qpt": 2, "cost_tsplit": 3, "tile_waves": 4, "lap_lds_kb": 5, "lap_wave_budget": 6, "no_fuse": 7, "no_direct": 8}
+KNOBS = {"lap_kernel": 0, "lap_max_waves": 1, "cost_qpt": 2, "cost_tsplit": 3, "tile_waves": 4, "lap_lds_kb": 5, "lap_wave_budget": 6, "no_fuse": 7, "no_direct": 8, "lap_plain_shape": 9}
 
 
 def set_knob(name: str, value: int):

@@ -32,6 +32,7 @@ extern "C" int dm_debug_set_knob(int knob, int value)
     case DM_KNOB_LAP_KERNEL:
     case DM_KNOB_LAP_MAX_WAVES:
     case DM_KNOB_LAP_WAVE_BUDGET:
+    case DM_KNOB_LAP_PLAIN_SHAPE:
     case DM_KNOB_LAP_LDS_KB: return dm::set_lap_knob(knob, value);
     case DM_KNOB_COST_QPT:
     case DM_KNOB_COST_TSPLIT:

@@ -50,6 +50,7 @@ constexpr int GENERIC_MAX = 4096;
 int g_lap_wave_budget = 0;   // 0: automatic (12288); otherwise wavefronts a launch of lap_block_kernel may ask for
 int g_lap_lds_kb = 0;        // 0: automatic; otherwise LDS budget per problem in KB (tuning knob)
 int g_lap_max_waves = 16;   // wavefronts per problem in lap_block_kernel (tuning knob)
+int g_lap_plain_shape = 0;   // testing aid.  1: one wavefront per 64-column slice up to 16; 2..16: exactly that many wavefronts
 int g_lap_mode = 0;   // 0: automatic; 1: list-order kernel only; 2: workgroup kernel; 3: wavefront kernel
 
 // Diagnostic build only (-DDM_LAP_STAMPS): cycle stamps around the segments of a step.
@@ -608,8 +609,11 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
 #endif
     // The solver proper, compiled twice: with every row of the block resident in LDS (the usual case)
     // the per-step choice of where a row lives disappears from the step.
-    auto solve = [&](auto all_resident) __attribute__((always_inline)) -> bool {
+    // NC: the columns per thread that this WAVEFRONT really has (the rest of its NCOL lie past the last column: with
+    // a thread count that is not a multiple of what the columns need, only the first wavefronts own NCOL columns).
+    auto solve = [&](auto all_resident, auto columns_here) __attribute__((always_inline)) -> bool {
         constexpr bool ALLRES = decltype(all_resident)::value;
+        constexpr int NC = decltype(columns_here)::value;
         int par = 0;
         unsigned scanned = 0;      // bit k: this thread's column k has been scanned (parked) in the current row
         for (int cur = 0; cur < nr; ++cur) {
@@ -624,42 +628,42 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
 #endif
                 const double ui = u[i];
                 const int jl_read = remaining[n - 1];     // column at the last list position
-                float c[NCOL];
+                float c[NC];
                 if (ALLRES || i < R) {
                     const float *row = crow + i * ls;
 #pragma unroll
-                    for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+                    for (int k = 0; k < NC; ++k) c[k] = row[jc[k]];
                 } else {
                     const float *row = cg + (size_t)i * qs;
 #pragma unroll
-                    for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+                    for (int k = 0; k < NC; ++k) c[k] = row[jc[k]];
                     if (!FUSED && i == cur) {     // the only full read of a row that is not resident: validate it here
                         bool badrow = false;
 #pragma unroll
-                        for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
+                        for (int k = 0; k < NC; ++k) badrow |= cost_is_invalid(c[k]);
                         if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
                     }
                 }
                 DM_STAMP(0)
                 double lmin = INF;
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
+                for (int k = 0; k < NC; ++k) {
                     const double r = ((min_val + (double)c[k]) - ui) - v[k];   // +inf for parked columns
                     const bool better = r < spc[k];
                     spc[k] = better ? r : spc[k];
                     pth[k] = better ? i : pth[k];
-                    lmin = (NCOL == 1) ? spc[k] : fmin(lmin, spc[k]);
+                    lmin = (NC == 1) ? spc[k] : fmin(lmin, spc[k]);
                 }
                 // the lane's candidate among its own columns (list-position rule on ties)
                 unsigned key = 0;
                 int cj = -1, cr = -1;
-                if (NCOL == 1) {
+                if (NC == 1) {
                     key = (r4c[0] == -1) ? (unsigned)(nc + 1 + posr[0]) : (unsigned)(nc - posr[0]);
                     cj = tid;
                     cr = r4c[0];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < NCOL; ++k) {
+                    for (int k = 0; k < NC; ++k) {
                         const bool hit = spc[k] == lmin;
                         const unsigned kk = (r4c[k] == -1) ? (unsigned)(nc + 1 + posr[k]) : (unsigned)(nc - posr[k]);
                         if (hit && kk > key) { key = kk; cj = tid + BS * k; cr = r4c[k]; }
@@ -715,7 +719,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 if (lane == 0) remaining[pw] = jl;
                 --n;
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
+                for (int k = 0; k < NC; ++k) {
                     const int j = tid + BS * k;
                     posr[k] = (j == jl) ? pw : posr[k];
                     if (j == jw) {       // park the column in its owner's registers
@@ -739,7 +743,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 // assignment of that column; list and positions are untouched.
                 // No barrier: every wave writes the shared words itself.
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
+                for (int k = 0; k < NC; ++k) {
                     if (tid + BS * k == sink) r4c[k] = cur;
                     spc[k] = INF;
                 }
@@ -750,7 +754,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
+                for (int k = 0; k < NC; ++k) {
                     const int j = tid + BS * k;
                     if ((scanned >> k) & 1u) {      // a column scanned in this row (all of them are assigned)
                         const double d = min_val - spc_real[k];
@@ -777,7 +781,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 // refresh the assignments of the scanned columns and of the sink (every owner for its own
                 // columns, in parallel); list and positions back to initial
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) {
+                for (int k = 0; k < NC; ++k) {
                     const int j = tid + BS * k;
                     if ((scanned >> k) & 1u) {
                         r4c[k] = row4col[j];
@@ -788,7 +792,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 scanned = 0;
                 for (int e = n + tid; e < nc; e += BS) remaining[e] = nc - 1 - e;
 #pragma unroll
-                for (int k = 0; k < NCOL; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
+                for (int k = 0; k < NC; ++k) { posr[k] = nc - 1 - (tid + BS * k); spc[k] = INF; }
                 // No barrier here: before the barrier of the next row's first step a wave reads only u[cur + 1]
                 // (untouched so far), cost rows and the last list slot, which it restores itself.
                 if (lane == 0) remaining[nc - 1] = 0;
@@ -797,7 +801,19 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
 
         return true;
     };
-    if (!(R >= nr ? solve(std::true_type{}) : solve(std::false_type{}))) return;
+    // Wavefronts whose last column slice lies entirely past the end run the solver for one column per thread less
+    // (same barriers, fewer instructions: the step is bound by instruction issue on the SIMDs its wavefronts share).
+    constexpr bool CAN_TRIM = NCOL >= 2 && NCOL <= 4;
+    constexpr int NTRIM = CAN_TRIM ? NCOL - 1 : NCOL;
+    const bool trimmed = CAN_TRIM && __builtin_amdgcn_readfirstlane(wave) * 64 + BS * (NCOL - 1) >= nc;
+    bool solved;
+    if (R >= nr)
+        solved = trimmed ? solve(std::true_type{}, std::integral_constant<int, NTRIM>{})
+                         : solve(std::true_type{}, std::integral_constant<int, NCOL>{});
+    else
+        solved = trimmed ? solve(std::false_type{}, std::integral_constant<int, NTRIM>{})
+                         : solve(std::false_type{}, std::integral_constant<int, NCOL>{});
+    if (!solved) return;
 
     __syncthreads();
 #ifdef DM_LAP_STAMPS
@@ -1021,6 +1037,22 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
     if (P * need > wave_budget) w = wave_budget / P;
     if (w > g_lap_max_waves) w = g_lap_max_waves;
     if (w < 1) w = 1;
+    // Few problems (every 64-column slice could have a wavefront of its own): more than twelve wavefronts per
+    // problem -- three per SIMD -- cost more than they bring, because a step takes as long as the wavefront that shares
+    // its SIMD with the most others (the SIMD serves the oldest first; measured: wavefronts 0-3 reach the step's
+    // barrier together, 4-7 some 220 cycles later, 8-11 some 470).  With 13 to 16 slices the problem gets twelve
+    // wavefronts and the slices left over are second columns of the first ones (Q = 900: 114 us for a problem with
+    // 100 targets against 127 us with 15 wavefronts and 123 us with 8 x 2 columns; Q = 1024: 70 / 76 / 73).  The
+    // wavefronts without a second column run the solver compiled for one (lap_block_kernel, `trimmed`).
+    if (g_lap_plain_shape != 1 && P * need <= wave_budget && g_lap_max_waves == 16) {
+        const int exact = g_lap_plain_shape > 1 ? std::min(g_lap_plain_shape, need)      // testing aid
+                                                : ((need > 12 && need <= 16) ? 12 : 0);
+        if (exact > 0 && (need + exact - 1) / exact <= BLOCK_MAX_NCOL_WIDE) {
+            *ncol = (need + exact - 1) / exact;
+            *waves = exact;
+            return;
+        }
+    }
     int n = (need + (int)w - 1) / (int)w;
     for (int c : NCOL_CLASSES) if (c >= n) { n = c; break; }
     *ncol = n;
@@ -1090,6 +1122,10 @@ int set_lap_knob(int knob, int value)
     case DM_KNOB_LAP_LDS_KB:
         if (value < 0 || value > 80) return DM_E_INVALID_ARG;
         g_lap_lds_kb = value;
+        return DM_OK;
+    case DM_KNOB_LAP_PLAIN_SHAPE:
+        if (value < 0 || value > 16) return DM_E_INVALID_ARG;
+        g_lap_plain_shape = value;
         return DM_OK;
     case DM_KNOB_LAP_MAX_WAVES:
         if (value < 0 || value > 16) return DM_E_INVALID_ARG;

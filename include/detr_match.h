@@ -312,6 +312,9 @@ int dm_profile_read(float *cost_ms, float *lap_ms);
 #define DM_KNOB_LAP_LDS_KB 5     /* 1..80: LDS budget per problem of the register assignment kernels, in KB */
 #define DM_KNOB_LAP_WAVE_BUDGET 6  /* wavefronts one launch of the workgroup-per-problem kernel may ask for */
 #define DM_KNOB_DIRECT_TARGETS 8  /* 1: dm_match_targets_f32 packs the targets whatever the shapes */
+#define DM_KNOB_LAP_PLAIN_SHAPE 9  /* workgroup-per-problem kernel with few problems in flight.  1: one wavefront per 64-column
+                                      slice (up to 16); 2..16: exactly that many wavefronts (automatic: at most twelve, the first
+                                      ones take the slices left over as second columns) */
 #define DM_KNOB_FUSE 7           /* 1: dm_match_fused_f32 takes the two-kernel path whatever the shapes */
 int dm_debug_set_knob(int knob, int value);
 

@@ -77,6 +77,37 @@ def test_fused_equals_two_kernel_path_on_workloads(name, batch):
         _assert_identical(wave, plain)
 
 
+@pytest.mark.parametrize("name,batch,queries", [("cfg2", 16, None), ("cfg3_hw", 8, None), ("cfg4", 8, None),
+                                                ("cfg2", 8, 832), ("cfg2", 8, 1024)])
+def test_wavefront_counts_do_not_change_the_pairs(name, batch, queries):
+    """The workgroup kernel with every wavefront count per problem: wavefronts whose second (third) column
+    slice lies past the last query run the solver compiled for fewer columns, and sets narrower than the
+    launch's shape leave whole wavefronts without a real column.  Same pairs as the one-wavefront-per-slice
+    shape, in the one-kernel and the two-kernel path."""
+    import dataclasses
+
+    import detr_amd
+    from detr_amd import synth
+
+    if queries is not None:
+        base = synth.WORKLOADS[name]
+        synth.WORKLOADS[name] = dataclasses.replace(base, set_queries=[queries] * 3)
+    try:
+        wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    finally:
+        if queries is not None:
+            synth.WORKLOADS[name] = base
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    want, _ = _both(matcher, sets, targets, lap_plain_shape=1)
+    automatic, plain = _both(matcher, sets, targets)
+    _assert_identical(automatic, want)
+    _assert_identical(plain, want)
+    for waves in (2, 3, 5, 7, 8, 11, 12, 13, 16):
+        fused, plain = _both(matcher, sets, targets, lap_plain_shape=waves)
+        _assert_identical(fused, want)
+        _assert_identical(plain, want)
+
+
 def test_fused_path_reports_the_reference_errors():
     """Degenerate prediction boxes of an image WITHOUT targets, a label out of range, a NaN logit:
     the fused kernels raise what the two-kernel path raises."""

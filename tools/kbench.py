@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--targets", type=int, default=None, help="the same number of targets for every image")
+    ap.add_argument("--queries", type=int, default=None, help="this many queries in every output set instead of the workload's")
     ap.add_argument("--which", default="cost,lap,both,fused")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-shape knob, e.g. lap_kernel=3, lap_max_waves=5, cost_tsplit=2, tile_waves=8")
@@ -35,6 +36,10 @@ def main():
     for kv in args.knob:
         name, value = kv.split("=")
         detr_amd._lib.set_knob(name, int(value))
+    if args.queries is not None:
+        import dataclasses
+        base = synth.WORKLOADS[args.workload]
+        synth.WORKLOADS[args.workload] = dataclasses.replace(base, set_queries=[args.queries] * len(base.set_queries))
     counts = None
     if args.targets is not None:
         counts = [args.targets] * (args.batch or synth.WORKLOADS[args.workload].batch)
