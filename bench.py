@@ -381,10 +381,16 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        # one kernel per step: the library computed the cost blocks inside the assignment kernel (C <= 4, every
-        # T < Q, few enough problems for one workgroup each) -- then nothing ran between the first two events
-        fused = (wl.n_logits <= 4 and max(sizes) <= 256 and all(q > max(sizes) for q in wl.set_queries)
-                 and cost_ms_avg < 2e-3)
+        # one kernel per step: the library computes the cost blocks inside the assignment kernel (C <= 4, every
+        # T < Q, few enough problems for one workgroup each); asked of the library itself
+        from detr_amd._lib import DmSet
+        arr = (DmSet * len(sets))()
+        for s_, q in enumerate(wl.set_queries):
+            arr[s_].Q, arr[s_].q_stride = q, (q + 31) & ~31
+        cost_sets = ctypes.c_int(-1)
+        rc = detr_amd.lib.dm_match_plan(arr, len(sets), B, wl.n_logits, max(sizes), ctypes.byref(cost_sets))
+        assert rc == 0, rc
+        fused = cost_sets.value == 0
         # logits + boxes of every prediction, labels + boxes of every target per set, two int64 indices per match
         step_bytes = sum(B * q * (wl.n_logits * 4 + 16) + sum(sizes) * 24 + 16 * sum(min(q, t) for t in sizes)
                          for q in wl.set_queries)

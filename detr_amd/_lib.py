@@ -43,7 +43,7 @@ class DmParams(ctypes.Structure):
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_pack_targets", "dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_targets_f32", "dm_match_noalloc_f32",
-           "dm_profile_enable", "dm_profile_read",
+           "dm_profile_enable", "dm_profile_read", "dm_match_plan",
            "dm_debug_set_knob",
            "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
            "dm_atss_f32", "dm_frcnn_f32", "dm_frcnn_dense_i64"]
@@ -99,6 +99,8 @@ def _load():
     lib.dm_frcnn_dense_i64.restype = ctypes.c_int
     lib.dm_frcnn_dense_i64.argtypes = [isetp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp,
                                        ctypes.c_int64, vp, vp]
+    lib.dm_match_plan.restype = ctypes.c_int
+    lib.dm_match_plan.argtypes = [setp, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int)]
     lib.dm_debug_set_knob.restype = ctypes.c_int
     lib.dm_debug_set_knob.argtypes = [ctypes.c_int, ctypes.c_int]
     lib.dm_profile_enable.restype = ctypes.c_int

@@ -142,6 +142,20 @@ extern "C" int dm_match_fused_f32(const DmSet *sets, int S, int B, int C, const 
     return rc;
 }
 
+extern "C" int dm_match_plan(const DmSet *sets, int S, int B, int C, int max_T, int *cost_sets)
+{
+    if (S < 0 || B < 0 || C < 1 || max_T < 0 || !cost_sets || (S > 0 && !sets)) return DM_E_INVALID_ARG;
+    *cost_sets = S;
+    if (S == 0 || g_no_fuse || !dm::lap_can_fuse(C, max_T) || S > 4096) return DM_OK;
+    unsigned char needs_cost[4096];
+    int rc = dm::lap_plan(sets, S, B, max_T, needs_cost);
+    if (rc != DM_OK) return rc;
+    int n = 0;
+    for (int s = 0; s < S; ++s) n += needs_cost[s] ? 1 : 0;
+    *cost_sets = n;
+    return DM_OK;
+}
+
 // dm_pack_targets + dm_match_fused_f32 in one call -- and, when the step runs as one fused kernel and the batch
 // fits the kernel-argument table, without the packing: the kernel reads every image's targets through the
 // pointers it is handed.

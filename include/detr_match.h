@@ -301,6 +301,14 @@ int dm_profile_enable(int on);
 int dm_profile_read(float *cost_ms, float *lap_ms);
 
 /*
+ * Measurement aid (no counterpart in the reference): how a dm_match_fused_f32 / dm_match_targets_f32 call of this
+ * shape would run.  *cost_sets = the number of the S output sets whose cost blocks go through the cost kernel and
+ * memory first (0: every assignment workgroup computes its own, the call is assignment launches only).  Launches
+ * nothing.  Only Q and q_stride of the sets are read.
+ */
+int dm_match_plan(const DmSet *sets, int S, int B, int C, int max_T, int *cost_sets);
+
+/*
  * Testing / tuning aid: launch-shape knobs.  None of them changes a result (the tests check that);
  * value 0 restores the automatic choice.  Returns DM_OK or DM_E_INVALID_ARG.  Not thread-safe.
  */

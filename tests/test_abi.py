@@ -127,3 +127,25 @@ def test_knobs_reject_values_they_do_not_know():
     assert lib.dm_debug_set_knob(detr_amd._lib.KNOBS["cost_tsplit"], 3) == -1
     for name in detr_amd._lib.KNOBS:
         detr_amd._lib.set_knob(name, 0)
+
+
+def test_match_plan_reports_which_sets_need_the_cost_kernel():
+    """dm_match_plan launches nothing: callable without a GPU."""
+    import ctypes
+
+    import detr_amd
+    from detr_amd._lib import DmSet, lib
+
+    def plan(queries, B, C, max_t):
+        arr = (DmSet * len(queries))()
+        for s, q in enumerate(queries):
+            arr[s].Q, arr[s].q_stride = q, (q + 31) & ~31
+        n = ctypes.c_int(-1)
+        assert lib.dm_match_plan(arr, len(queries), B, C, max_t, ctypes.byref(n)) == 0
+        return n.value
+
+    assert plan([600] * 6, 64, 2, 26) == 0            # one kernel: every workgroup computes its own cost block
+    assert plan([600] * 6, 64, 91, 26) == 6           # many classes: cost kernel first
+    assert plan([600] * 12, 1024, 2, 28) == 12        # thousands of problems: the one-wavefront kernel reads cost blocks
+    assert plan([300] * 6 + [20], 8, 2, 26) == 1      # T >= Q possible in the last set: the list-order kernel needs its blocks
+    assert lib.dm_match_plan(None, 1, 1, 2, 1, None) == -1
