@@ -282,15 +282,41 @@ class FlatMatches:
     Nothing here synchronises with the host."""
 
     def __init__(self, batch_idx, src_idx, tgt_idx, tgt_flat, packed, queries, raw=None, set_index=0):
-        self.batch_idx, self.src_idx, self.tgt_idx, self.tgt_flat = batch_idx, src_idx, tgt_idx, tgt_flat
+        # src_idx / tgt_idx / tgt_flat None: rows `set_index` of the launch's index buffer, sliced on first use
+        # (the fused consumers of detr_amd.losses read the buffer itself and never ask for them)
+        self.batch_idx, self._src, self._tgt, self._flat = batch_idx, src_idx, tgt_idx, tgt_flat
         self.packed, self.queries = packed, queries
-        # (index buffer [src (S*M) | tgt (S*M) | status], S) of the launch this set came from and the
+        # (index buffer [src (S*M) | tgt (S*M) | status (| flat (S*M))], S) of the launch this set came from and the
         # set's position in it: what detr_amd.losses hands to the fused consumer kernels
         self.raw, self.set_index = raw, set_index
 
+    def _row(self, part: int) -> torch.Tensor:
+        out, S = self.raw
+        M = self.packed.total
+        lo = (part * S + self.set_index) * M + (1 if part == 2 else 0)      # (the status word sits before the flat part)
+        return out[lo:lo + M]
+
+    @property
+    def src_idx(self) -> torch.Tensor:
+        if self._src is None:
+            self._src = self._row(0)
+        return self._src
+
+    @property
+    def tgt_idx(self) -> torch.Tensor:
+        if self._tgt is None:
+            self._tgt = self._row(1)
+        return self._tgt
+
+    @property
+    def tgt_flat(self) -> torch.Tensor:
+        if self._flat is None:
+            self._flat = self._row(2)
+        return self._flat
+
     @property
     def num_matched(self) -> int:
-        return int(self.src_idx.shape[0])
+        return self.packed.total if self._src is None else int(self._src.shape[0])
 
     def src_permutation_idx(self):
         """(batch_idx, src_idx), the reference's `_get_src_permutation_idx` (detr/loss.py:71-75)."""
@@ -722,15 +748,19 @@ class HungarianMatcher(torch.nn.Module):
             return []
         out, queries, _, _ = self._launch(outputs_list, packed, flat=True)
         M, sizes = packed.total, packed.sizes
-        both = out[:2 * S * M].view(2, S, M)
         batch_idx = packed.batch_index
-        flat_all = out[2 * S * M + 1:].view(S, M)             # written by the assignment kernel itself
+        raw = (out, S)
         result = []
+        both = flat_all = None
         for s, q in enumerate(queries):
-            src, tgt, flat = both[0, s], both[1, s], flat_all[s]
             if M == 0 or q >= packed.max_t:
-                result.append(FlatMatches(batch_idx, src, tgt, flat, packed, q, (out, S), s))
+                # every target of every image is matched: the set's rows of the buffer, sliced when asked for
+                result.append(FlatMatches(batch_idx, None, None, None, packed, q, raw, s))
                 continue
+            if both is None:
+                both = out[:2 * S * M].view(2, S, M)
+                flat_all = out[2 * S * M + 1:].view(S, M)             # written by the assignment kernel itself
+            src, tgt, flat = both[0, s], both[1, s], flat_all[s]
             # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
             keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
                                    for o, t in zip(packed.offsets_list[:-1], sizes)] + [np.zeros(0, np.int64)])
