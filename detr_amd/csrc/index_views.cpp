@@ -13,6 +13,12 @@
 //     one is made, finds the objects of the call before that free.  An object that is still
 //     referenced anywhere -- Python reference, C++ reference, weak reference -- is never touched; a
 //     fresh one takes its place in the pool.
+//   * the lists and tuples are recycled with them: when the caller has dropped the whole result of the call
+//     before the last (nobody holds the list of sets, a list of images or a tuple any more) and the new
+//     result has the same numbers of sets and images, the same containers are handed out again around the
+//     re-pointed tensors.  No container is allocated then, so the interpreter's cyclic collector -- which
+//     counts container allocations and, with tens of thousands per step, runs a full collection every few
+//     steps -- is not triggered by the matcher at all.
 //
 // The module also has the two per-tensor scans of a matcher call (scan_targets, scan_outputs): with 64
 // images and 6 output sets a call touches 140 tensors, and checking dtype / device / layout and taking
@@ -37,28 +43,34 @@ namespace {
 
 // strong references to the tensor objects handed out by the last two calls, used alternately
 std::vector<PyObject *> g_pools[2];
+// ... and to the list of sets each of the two calls returned (nullptr: none kept)
+PyObject *g_results[2] = {nullptr, nullptr};
 unsigned g_turn = 0;
+
+// Re-points tensor object `obj` at `n` elements of `storage` from `offset` if nobody but its `holders` known
+// owners (the pool, possibly a recycled tuple) references it.
+bool repoint(PyObject *obj, Py_ssize_t holders, const c10::Storage &storage, c10::DispatchKeySet keys, int64_t offset, int64_t n)
+{
+    PyObject **weak = Py_TYPE(obj)->tp_weaklistoffset ? PyObject_GET_WEAKREFS_LISTPTR(obj) : nullptr;
+    if (Py_REFCNT(obj) != holders || (weak && *weak)) return false;
+    const at::Tensor &t = THPVariable_Unpack(obj);
+    // (an object is only re-pointed at storage of the kind it was made for: its dispatch keys stay)
+    if (t.use_count() != 1 || t.weak_use_count() != 1 || t.key_set() != keys) return false;
+    c10::TensorImpl *impl = t.unsafeGetTensorImpl();
+    impl->set_storage_keep_dtype(storage);
+    impl->set_storage_offset(offset);
+    impl->set_sizes_contiguous({n});
+    return true;
+}
 
 // The tensor object at pool slot `slot`, viewing `n` elements of `storage` from element `offset`.
 // Returns a NEW reference (the pool keeps its own).
 PyObject *view_at(std::vector<PyObject *> &g_pool, size_t slot, const c10::Storage &storage, c10::DispatchKeySet keys, caffe2::TypeMeta dtype,
                   int64_t offset, int64_t n)
 {
-    if (slot < g_pool.size()) {
-        PyObject *obj = g_pool[slot];
-        PyObject **weak = Py_TYPE(obj)->tp_weaklistoffset ? PyObject_GET_WEAKREFS_LISTPTR(obj) : nullptr;
-        if (Py_REFCNT(obj) == 1 && (!weak || !*weak)) {
-            const at::Tensor &t = THPVariable_Unpack(obj);
-            // (an object is only re-pointed at storage of the kind it was made for: its dispatch keys stay)
-            if (t.use_count() == 1 && t.weak_use_count() == 1 && t.key_set() == keys) {
-                c10::TensorImpl *impl = t.unsafeGetTensorImpl();
-                impl->set_storage_keep_dtype(storage);
-                impl->set_storage_offset(offset);
-                impl->set_sizes_contiguous({n});
-                Py_INCREF(obj);
-                return obj;
-            }
-        }
+    if (slot < g_pool.size() && repoint(g_pool[slot], 1, storage, keys, offset, n)) {
+        Py_INCREF(g_pool[slot]);
+        return g_pool[slot];
     }
     at::Tensor t = at::detail::make_tensor<c10::TensorImpl>(c10::TensorImpl::VIEW, c10::Storage(storage), keys, dtype);
     c10::TensorImpl *impl = t.unsafeGetTensorImpl();
@@ -125,10 +137,50 @@ PyObject *index_pairs(PyObject *, PyObject *args)
     const caffe2::TypeMeta dtype = flat.dtype();
     const int64_t base = flat.storage_offset();
 
+    const unsigned turn = g_turn++ & 1u;
+    std::vector<PyObject *> &g_pool = g_pools[turn];
+    size_t slot = 0;
+
+    // The containers of the call before the last, if the caller has dropped all of them and the shape is the same:
+    // list of S lists of B tuples of the pool's tensors, nobody but this module (and each other) holding any of them.
+    PyObject *kept = g_results[turn];
+    bool reuse = kept && Py_REFCNT(kept) == 1 && PyList_GET_SIZE(kept) == S && g_pool.size() == (size_t)(2 * S * B);
+    for (int64_t s = 0; reuse && s < S; ++s) {
+        PyObject *per_image = PyList_GET_ITEM(kept, s);
+        reuse = PyList_CheckExact(per_image) && Py_REFCNT(per_image) == 1 && PyList_GET_SIZE(per_image) == B;
+        for (int64_t b = 0; reuse && b < B; ++b) {
+            PyObject *pair = PyList_GET_ITEM(per_image, b);
+            const size_t at = (size_t)(2 * (s * B + b));
+            reuse = PyTuple_CheckExact(pair) && Py_REFCNT(pair) == 1 && PyTuple_GET_SIZE(pair) == 2 &&
+                    PyTuple_GET_ITEM(pair, 0) == g_pool[at] && PyTuple_GET_ITEM(pair, 1) == g_pool[at + 1];
+        }
+    }
+    if (reuse) {
+        for (int64_t s = 0; s < S; ++s) {
+            PyObject *per_image = PyList_GET_ITEM(kept, s);
+            for (int64_t b = 0; b < B; ++b) {
+                const int64_t n = sizes[(size_t)b] < queries[(size_t)s] ? sizes[(size_t)b] : queries[(size_t)s];
+                const int64_t lo = base + s * M + offsets[(size_t)b];
+                PyObject *pair = PyList_GET_ITEM(per_image, b);
+                for (int side = 0; side < 2; ++side, ++slot) {
+                    const int64_t off = lo + (side ? S * M : 0);
+                    // held by the pool and by its tuple; anything more: somebody kept that tensor, it is left alone
+                    if (repoint(g_pool[slot], 2, storage, keys, off, n)) continue;
+                    PyObject *kept_tensor = PyTuple_GET_ITEM(pair, side);
+                    PyObject *fresh = view_at(g_pool, slot, storage, keys, dtype, off, n);      // a new object, also in the pool
+                    if (!fresh) { Py_CLEAR(g_results[turn]); return nullptr; }
+                    PyTuple_SET_ITEM(pair, side, fresh);       // (this module holds the only reference to the tuple)
+                    Py_DECREF(kept_tensor);
+                }
+            }
+        }
+        Py_INCREF(kept);
+        return kept;
+    }
+    Py_CLEAR(g_results[turn]);      // its tuples' references to the pool's tensors go with it
+
     PyObject *result = PyList_New(S);
     if (!result) return nullptr;
-    std::vector<PyObject *> &g_pool = g_pools[g_turn++ & 1u];
-    size_t slot = 0;
     for (int64_t s = 0; s < S; ++s) {
         PyObject *per_image = PyList_New(B);
         if (!per_image) { Py_DECREF(result); return nullptr; }
@@ -155,6 +207,8 @@ PyObject *index_pairs(PyObject *, PyObject *args)
         Py_DECREF(g_pool.back());
         g_pool.pop_back();
     }
+    Py_INCREF(result);
+    g_results[turn] = result;
     return result;
 }
 
@@ -162,6 +216,7 @@ PyObject *pool_size(PyObject *, PyObject *) { return PyLong_FromSize_t(g_pools[0
 
 PyObject *clear_pool(PyObject *, PyObject *)
 {
+    for (auto &kept : g_results) Py_CLEAR(kept);
     for (auto &pool : g_pools) {
         for (PyObject *o : pool) Py_DECREF(o);
         pool.clear();

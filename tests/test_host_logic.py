@@ -299,3 +299,54 @@ def test_launch_targets_refuses_what_it_cannot_launch():
         iv.launch_targets(outs, 3, total, max_t, pointers, meta, dummy, dummy, dummy, 1 << 20, 0, 0)
     with pytest.raises(ValueError):      # no entry point
         iv.launch_targets(outs, 2, total, max_t, pointers, meta, 0, dummy, dummy, 1 << 20, 0, 0)
+
+
+def test_index_pairs_recycles_containers_only_when_nobody_holds_them():
+    """The helper hands out the lists and tuples of the call before the last again when the caller has dropped
+    all of them and the shape is unchanged; a tensor, tuple or list that is still held is never touched."""
+    iv = pytest.importorskip("detr_amd._index_views")
+    S, B, M = 3, 4, 6
+    sizes, offs = [2, 0, 3, 1], [0, 2, 2, 5]
+
+    def make(val):
+        flat = torch.arange(2 * S * M + 1, dtype=torch.int64) + val
+        return flat, iv.index_pairs(flat, M, sizes, [10] * S, offs)
+
+    def expect(val, s, b, side):
+        return [val + side * S * M + s * M + offs[b] + k for k in range(sizes[b])]
+
+    def check(result, val):
+        for s in range(S):
+            for b in range(B):
+                assert result[s][b][0].tolist() == expect(val, s, b, 0)
+                assert result[s][b][1].tolist() == expect(val, s, b, 1)
+
+    iv.clear_pool()
+    try:
+        f1, r1 = make(0)
+        f2, r2 = make(100)
+        outer, inner = id(r1), [id(x) for x in r1]
+        del r1
+        f3, r3 = make(200)                       # the containers of the first call come back, around re-pointed tensors
+        assert id(r3) == outer and [id(x) for x in r3] == inner
+        check(r3, 200)
+        check(r2, 100)
+        keep = r2[1][2][0]                       # a tensor kept from a dropped result is left alone
+        del r2
+        f4, r4 = make(300)
+        assert keep.tolist() == expect(100, 1, 2, 0) and r4[1][2][0] is not keep
+        check(r4, 300)
+        held = r3[0]                             # a list of images kept: nothing of that result is reused
+        del r3
+        f5, r5 = make(400)
+        assert held[0][0].tolist() == expect(200, 0, 0, 0) and held[2][1].tolist() == expect(200, 0, 2, 1)
+        check(r5, 400)
+        r4[0].append(None)                       # a result the caller changed before dropping it
+        del r4
+        f6, r6 = make(500)
+        assert all(len(x) == B for x in r6)
+        check(r6, 500)
+        other = iv.index_pairs(torch.arange(100, dtype=torch.int64), 3, [1, 2], [5, 5], [0, 1])      # another shape
+        assert len(other) == 2 and other[1][1][1].tolist() == [10, 11]
+    finally:
+        iv.clear_pool()
