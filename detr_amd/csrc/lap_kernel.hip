@@ -802,7 +802,8 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         return true;
     };
     // Wavefronts whose last column slice lies entirely past the end run the solver for one column per thread less
-    // (same barriers, fewer instructions: the step is bound by instruction issue on the SIMDs its wavefronts share).
+    // (same barriers; fewer instructions and a shorter dependency chain per step: measured 71 -> 56 us for six sets of
+    // 300 queries sharing a launch shaped for a seventh of 1050).
     constexpr bool CAN_TRIM = NCOL >= 2 && NCOL <= 4;
     constexpr int NTRIM = CAN_TRIM ? NCOL - 1 : NCOL;
     const bool trimmed = CAN_TRIM && __builtin_amdgcn_readfirstlane(wave) * 64 + BS * (NCOL - 1) >= nc;
