@@ -120,7 +120,9 @@ __device__ __forceinline__ bool several_lanes(unsigned long long mask)
 // j = l + 64*k, k < NCOL, and keeps their reduced cost, dual, assignment and predecessor in
 // registers.  A column that has been scanned (or lies past Q) is parked with reduced cost +inf
 // and dual -inf, which makes it inert in the scan without a mask test; its real values wait in
-// a shadow register pair until the row's dual update.  Per Dijkstra step the minimum is located
+// LDS, at the column's place in the row's scan order, until the row's dual update (in registers they
+// cost 4 VGPRs per column: 208 instead of 152 for ten columns, two wavefronts per SIMD instead of three).
+// Per Dijkstra step the minimum is located
 // with 32-bit DPP reductions on the order-preserving high word (low word and list-position tie
 // key only when needed).  No barrier: a single wave executes its LDS operations in order.
 template <int NCOL>
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 #endif
 
     double *u = reinterpret_cast<double *>(smem);           // [t_cap] row duals
-    int *col4row = reinterpret_cast<int *>(u + t_cap);      // [t_cap]
+    double *shadow = u + t_cap;                             // [t_cap][2] reduced cost and dual of the columns parked in the
+                                                            // current row, in scan order (registers hold +inf / -inf meanwhile)
+    int *col4row = reinterpret_cast<int *>(shadow + 2 * t_cap);      // [t_cap]
     int *sclist = col4row + t_cap;                          // [t_cap] columns scanned in the current row, in order
     int *row4col = sclist + t_cap;                          // [QCAP]
     int *pathL = row4col + QCAP;                            // [QCAP]
@@ -168,14 +172,14 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
     const int ls = linear ? qs : nc;                        // LDS row stride
     const int R = min(nr, lds_cost_floats / ls);            // rows resident in LDS
 
-    double v[NCOL], spc[NCOL], v_real[NCOL], spc_real[NCOL];
+    double v[NCOL], spc[NCOL];
     int r4c[NCOL], pth[NCOL], jc[NCOL];
 #pragma unroll
     for (int k = 0; k < NCOL; ++k) {
         const int j = lane + 64 * k;
         const bool ok = j < nc;
         v[k] = ok ? 0.0 : NEG_INF;
-        spc[k] = INF; v_real[k] = 0.0; spc_real[k] = INF; r4c[k] = -1; pth[k] = -1;
+        spc[k] = INF; r4c[k] = -1; pth[k] = -1;
         jc[k] = min(j, nc - 1);      // columns past the end alias the last one and stay parked
         if (ok) {
             row4col[j] = -1;
@@ -319,17 +323,18 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
             if (rw == -1) { sink = jw; DM_STAMP(4) break; }
             if (pw < 0) pw = __builtin_amdgcn_readfirstlane(pos[jw]);
             // swap-with-last removal of column jw from the list
+            const int scan_at = nc - n;      // how many columns this row has scanned before this one
             if (lane == 0) {
                 remaining[pw] = jl;
                 pos[jl] = pw;
-                sclist[nc - n] = jw;
+                sclist[scan_at] = jw;
             }
             --n;
-            // park the column in its owner's registers
+            // park the column: its real values wait in LDS, at its place in the scan order
             with_static_index(jw >> 6, [&](auto kc) {
                 constexpr int K = decltype(kc)::value;
                 if (lane == (jw & 63)) {
-                    spc_real[K] = spc[K]; v_real[K] = v[K];
+                    shadow[2 * scan_at] = spc[K]; shadow[2 * scan_at + 1] = v[K];
                     spc[K] = INF; v[K] = NEG_INF;
                 }
             }, KSeq{});
@@ -362,9 +367,9 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
                 with_static_index(j >> 6, [&](auto kc) {
                     constexpr int K = decltype(kc)::value;
                     if (lane == (j & 63)) {
-                        const double d = min_val - spc_real[K];
+                        const double d = min_val - shadow[2 * e];
                         u[r4c[K]] += d;
-                        v[K] = v_real[K] - d;
+                        v[K] = shadow[2 * e + 1] - d;
                         pathL[j] = pth[K];
                     }
                 }, KSeq{});
@@ -996,7 +1001,7 @@ int launch_wave(const DmSetArray &arr, int n, const LapArgs &a, int max_Q, int m
 {
     const int fast_T = a.max_T < max_Q ? a.max_T : max_Q - 1;     // largest row count this kernel can meet
     const int t_cap = (fast_T + 3) & ~3;
-    const size_t fixed = (size_t)t_cap * (8 + 4 + 4) + (size_t)4 * 64 * NCOL * 4;
+    const size_t fixed = (size_t)t_cap * (8 + 16 + 4 + 4) + (size_t)4 * 64 * NCOL * 4;
     size_t want = (size_t)fast_T * max_stride * sizeof(float);
     // few problems: two workgroups per CU can share the 160 KB of LDS and keep their cost rows in
     // it; many: resident wavefronts per SIMD matter more than resident rows (measured 1.8x at 12 288
@@ -1226,11 +1231,12 @@ static int make_plan(const DmSet *sets, int S, int B, int max_T, Plan &plan)
         // wavefront per problem (throughput)
         int ncol = ncol_class(Q), waves = 1;
         const long long P = (long long)total * B;
-        // crossover measured at Q=600, T~16: 20480 column slices; problems with many rows (T up to
-        // 100 at Q=900) stay faster in the workgroup kernel well beyond that
+        // crossover measured at Q=600, T~16: about 2800 problems (2688: 104 vs 109 us, 3072: 116 vs 101 us), i.e.
+        // 28672 column slices; problems with many rows (T up to 100 at Q=900) stay faster in the workgroup kernel
+        // well beyond that
         const long long slices = P * ((Q + 63) / 64);
         const bool use_block = g_lap_mode == 2 || Q > FAST_MAX_Q ||
-                               (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 20480));
+                               (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 28672));
         if (use_block) pick_shape(Q, P, &ncol, &waves);
         Launch l{use_block, ncol, waves, Q, Q, {}};
         for (int s = s0; s <= S; ++s) {
