@@ -151,7 +151,7 @@ __device__ __forceinline__ void small_class_costs(const float (&x)[4], const int
 // The targets of up to DIRECT_MAX_IMAGES images as the caller holds them -- one labels and one boxes tensor per
 // image -- with the offsets and the processing order, all travelling in the kernel-argument segment: a
 // kernel that takes them needs no packed copy of the targets and no upload.
-constexpr int DIRECT_MAX_IMAGES = 96;
+constexpr int DIRECT_MAX_IMAGES = 128;      // (3076 bytes of the 4 KB a kernel may take as arguments)
 struct DirectTargets {
     const int64_t *labels[DIRECT_MAX_IMAGES];
     const float *boxes[DIRECT_MAX_IMAGES];

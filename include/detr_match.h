@@ -169,7 +169,7 @@ int dm_match_fused_f32(const DmSet *sets, int S, int B, int C,
 
 /*
  * A whole matcher call from the reference's own inputs: dm_pack_targets followed by dm_match_fused_f32 -- or,
- * when the step runs as one fused kernel and B <= 96, that kernel alone, reading every image's labels and boxes
+ * when the step runs as one fused kernel and B <= 128, that kernel alone, reading every image's labels and boxes
  * through the pointers (they travel, with offsets and order, as kernel arguments): no packed copy, no second launch.
  *   pointers, meta              as for dm_pack_targets
  *   labels_buf, boxes_buf, meta_buf   device room for the packed targets (M int64, M x 4 float 16-byte aligned,

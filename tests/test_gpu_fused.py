@@ -136,10 +136,10 @@ def test_fused_path_reports_the_reference_errors():
     assert len(ok[0]) == 4
 
 
-@pytest.mark.parametrize("name,batch", [("cfg1", None), ("cfg2", None), ("cfg3_hw", 16), ("cfg5", 96), ("cfg5", 128)])
+@pytest.mark.parametrize("name,batch", [("cfg1", None), ("cfg2", None), ("cfg3_hw", 16), ("cfg5", 128), ("cfg5", 160)])
 def test_targets_read_in_place_equal_packed_targets(name, batch):
     """A step that runs as one fused kernel reads every image's labels and boxes through the pointers it is handed
-    (up to 96 images); with more images, or with the knob, the targets are packed first.  Same indices."""
+    (up to 128 images); with more images, or with the knob, the targets are packed first.  Same indices."""
     import detr_amd
     from detr_amd import synth
 
@@ -147,7 +147,7 @@ def test_targets_read_in_place_equal_packed_targets(name, batch):
     matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
     direct = matcher.match_many(sets, targets)
     was_direct = matcher._packed._unpacked is not None          # the packed arrays were never filled
-    assert was_direct == (len(targets) <= 96)
+    assert was_direct == (len(targets) <= 128)
     detr_amd._lib.set_knob("no_direct", 1)
     try:
         packed_first = matcher.match_many(sets, [dict(t) for t in targets[:-1]] + [
@@ -219,8 +219,8 @@ def test_one_call_launch_equals_the_general_path():
         assert len(calls) == 2 and calls[0] > 0 and calls[1] == 0        # workspace request, then the launch
         b = fast.match_many(sets[:2], targets)                           # smaller step, workspace large enough
         assert calls[2:] == [0]
-        # 128 images: more than the kernel-argument table holds -> the call reports that it has to pack
-        wl5, sets5, targets5 = synth.make_workload("cfg5", device="cuda", batch=128)
+        # 160 images: more than the kernel-argument table holds -> the call reports that it has to pack
+        wl5, sets5, targets5 = synth.make_workload("cfg5", device="cuda", batch=160)
         big = detr_amd.HungarianMatcher(**wl5.matcher_kwargs)
         del calls[:]
         c = big.match_many(sets5[:2], targets5)
