@@ -429,15 +429,17 @@ typedef int (*MatchTargetsFn)(const void *sets, int S, int B, int C, const uint6
 // buffers for packed targets.  Returns
 //   None                        unusual output sets, or not on device `device_index`: nothing done
 //   int                         floats of workspace the call needs, more than it was handed: nothing done
-//   (host, queries, rc)         rc as returned by the entry point; 1 (DM_NEED_BUFFERS): nothing was launched
+//   (host, queries, rc, packed) rc as returned by the entry point; 1 (DM_NEED_BUFFERS): the step has to pack its targets and
+//                               was handed no room for them (labels_buf, boxes_buf, meta_buf: optional trailing
+//                               arguments, device addresses), nothing was launched; packed: the targets were packed
 PyObject *launch_targets(PyObject *, PyObject *args)
 {
     PyObject *outputs, *pointers, *meta;
     long long batch, M, max_t, ws_floats;
-    unsigned long long entry, params, workspace, stream;
+    unsigned long long entry, params, workspace, stream, labels_buf = 0, boxes_buf = 0, meta_buf = 0;
     int device_index;
-    if (!PyArg_ParseTuple(args, "OLLLSSKKKLKi", &outputs, &batch, &M, &max_t, &pointers, &meta, &entry, &params,
-                          &workspace, &ws_floats, &stream, &device_index))
+    if (!PyArg_ParseTuple(args, "OLLLSSKKKLKi|KKK", &outputs, &batch, &M, &max_t, &pointers, &meta, &entry, &params,
+                          &workspace, &ws_floats, &stream, &device_index, &labels_buf, &boxes_buf, &meta_buf))
         return nullptr;
     if (batch < 1 || M < 0 || batch > INT32_MAX / 2 || max_t > INT32_MAX || !entry || !params ||
         PyBytes_GET_SIZE(pointers) != 16 * batch || PyBytes_GET_SIZE(meta) != 4 * (2 * batch + 1)) {
@@ -473,14 +475,15 @@ PyObject *launch_targets(PyObject *, PyObject *args)
     const int rc = reinterpret_cast<MatchTargetsFn>(entry)(
         r.recs.data(), (int)S, (int)batch, (int)r.C, reinterpret_cast<const uint64_t *>(PyBytes_AS_STRING(pointers)),
         reinterpret_cast<const int32_t *>(PyBytes_AS_STRING(meta)), (int)max_t, reinterpret_cast<const void *>(params),
-        nullptr, nullptr, nullptr, reinterpret_cast<float *>(workspace), base + 1, base + 1 + SM, nullptr,
+        reinterpret_cast<int64_t *>(labels_buf), reinterpret_cast<float *>(boxes_buf), reinterpret_cast<int32_t *>(meta_buf),
+        reinterpret_cast<float *>(workspace), base + 1, base + 1 + SM, nullptr,
         reinterpret_cast<int32_t *>(base), reinterpret_cast<void *>(stream), &packed);
     PyObject *ht = THPVariable_Wrap(host);
     if (!ht) {
         Py_DECREF(r.queries);
         return nullptr;
     }
-    return Py_BuildValue("(NNi)", ht, r.queries, rc);
+    return Py_BuildValue("(NNii)", ht, r.queries, rc, packed);
 }
 
 PyMethodDef methods[] = {

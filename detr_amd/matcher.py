@@ -377,7 +377,6 @@ class HungarianMatcher(torch.nn.Module):
         self._buffers = {}
         self._packed = None
         self._params_cache = None
-        self._skip_fast = 0
 
     def __getstate__(self):
         # per-device events and buffers, the packed targets and the last status view belong to this
@@ -392,7 +391,7 @@ class HungarianMatcher(torch.nn.Module):
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None), ("_skip_fast", 0),
+        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None),
                             ("through_ops", False), ("indices_to_host", True)):
             self.__dict__.setdefault(name, value)
 
@@ -465,29 +464,32 @@ class HungarianMatcher(torch.nn.Module):
         pending = packed.__dict__.get("_unpacked")
         if pending is None or _index_views is None:
             return None
-        if self._skip_fast > 0:
-            self._skip_fast -= 1
-            return None
         index = torch.cuda.current_device()
         ws = self._buffers.get(index)
         cost = ws["cost"] if ws is not None else None
         self._params_ref()
         while True:
+            # (room for the packed form of the targets is only allocated when a call says that it has to pack)
+            room = packed._pointers[:3] if packed._pointers is not None else (0, 0, 0)
             r = _index_views.launch_targets(outputs_list, packed.batch, packed.total, packed.max_t, pending[0], pending[1],
                                             _TARGETS_ENTRY, self._params_cache[3], cost.data_ptr() if cost is not None else 0,
-                                            cost.shape[0] if cost is not None else 0, _raw_stream(index), index)
+                                            cost.shape[0] if cost is not None else 0, _raw_stream(index), index, *room)
             if r is None:
                 return None
             if type(r) is int:          # a larger workspace is needed: nothing was launched
                 cost = self._workspace(device, 0, r)["cost"]
                 continue
+            if r[2] == _lib.NEED_BUFFERS and packed._pointers is None:      # nothing was launched either
+                packed._pack_buffer()
+                continue
             break
-        host, queries, rc = r
-        if rc == _lib.NEED_BUFFERS:     # the step has to pack its targets: not this path's business for a while
-            self._skip_fast = 64
-            return None
+        host, queries, rc, did_pack = r
         if rc:
             _lib.check(rc, "dm_match_targets_f32")
+        if did_pack:
+            if packed.total == 0:
+                packed._buf[:packed._layout[2]].zero_()
+            packed._unpacked = None
         self.__dict__["last_status"] = None
         return host, queries
 

@@ -193,7 +193,7 @@ def test_indices_stored_to_host_memory_equal_copied_indices(name, batch):
 def test_one_call_launch_equals_the_general_path():
     """The usual step goes through ONE call of the host helper (output scan, pinned result tensor, entry point);
     everything else through the Python path.  Same tuples; the helper asks for a larger workspace instead of
-    launching into a small one, and a step that has to pack its targets leaves that path alone for a while."""
+    launching into a small one, and a step that has to pack its targets does so inside the same call once it has room for them."""
     import detr_amd
     import detr_amd.matcher as mm
     from detr_amd import synth
@@ -219,15 +219,17 @@ def test_one_call_launch_equals_the_general_path():
         assert len(calls) == 2 and calls[0] > 0 and calls[1] == 0        # workspace request, then the launch
         b = fast.match_many(sets[:2], targets)                           # smaller step, workspace large enough
         assert calls[2:] == [0]
-        # 160 images: more than the kernel-argument table holds -> the call reports that it has to pack
+        # 160 images: more than the kernel-argument table holds -> the call reports that it has to pack, gets room
+        # for the packed targets and is made again
         wl5, sets5, targets5 = synth.make_workload("cfg5", device="cuda", batch=160)
         big = detr_amd.HungarianMatcher(**wl5.matcher_kwargs)
         del calls[:]
         c = big.match_many(sets5[:2], targets5)
-        assert calls[-1] == detr_amd._lib.NEED_BUFFERS and big._skip_fast == 64
+        assert calls[-2:] == [detr_amd._lib.NEED_BUFFERS, 0] and big._packed._unpacked is None
         n = len(calls)
-        big.match_many(sets5[:2], targets5[:-1] + [dict(targets5[-1], labels=targets5[-1]["labels"].clone())])
-        assert len(calls) == n and big._skip_fast == 63                  # not tried again right away
+        c2 = big.match_many(sets5[:2], targets5[:-1] + [dict(targets5[-1], labels=targets5[-1]["labels"].clone())])
+        assert calls[n:] == [detr_amd._lib.NEED_BUFFERS, 0]                  # new targets: packed again, in the same call
+        _assert_identical(c, c2)
     finally:
         mm._index_views = mm._index_views_real
         del mm._index_views_real
