@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of HungarianMatcher (every path the shapes select: one kernel with the targets read in place,
 packed targets, two kernels, the list-order kernel for T >= Q, many classes) against the CPU oracle: random class
-counts, query counts, batch sizes, weights, focal parameters, empty images, images with more targets than queries,
+counts, query counts (also different ones for the output sets of a call), batch sizes, weights, focal parameters, empty images, images with more targets than queries,
 python-style negative labels.  An image counts as a mismatch when its pairs differ AND their total cost on the
 oracle's cost block differs by more than 1e-5 relative."""
 import os
@@ -26,15 +26,17 @@ while time.time() < t_end:
         t_say += 20
     cls_loss = str(rng.choice(["ce", "focal"]))
     C = int(rng.choice([1, 2, 3, 4, 5, 17, 91, 92, 700])) if cls_loss == "focal" else int(rng.choice([2, 3, 4, 7, 92, 650]))
-    Q = int(rng.choice([3, 10, 64, 65, 100, 300, 600, 900, 1100]))
-    B = int(rng.choice([1, 2, 5, 16, 40, 100]))
+    Q = int(rng.choice([3, 10, 64, 65, 100, 300, 600, 832, 900, 1024, 1100]))
+    B = int(rng.choice([1, 2, 5, 16, 40, 100, 128, 160]))      # (128: the most the in-place target table holds)
     if C >= 91:
         B = min(B, 5)
     S = int(rng.integers(1, 4))
+    # output sets of different widths in one call (decoder layers beside a first stage): one launch shaped for the widest
+    widths = [Q if rng.random() < 0.7 else int(rng.choice([50, 300, 600, 1050])) for _ in range(S)]
     counts = rng.poisson(rng.choice([3, 12, 30]), B)
     counts[rng.random(B) < 0.15] = 0
     if rng.random() < 0.2:
-        counts[rng.integers(0, B)] = Q + int(rng.integers(0, 5))          # an image with T >= Q
+        counts[rng.integers(0, B)] = min(widths) + int(rng.integers(0, 5))          # an image with T >= Q
     kw = dict(cls_loss=cls_loss, cost_class=float(rng.choice([1.0, 2.0, 0.5])), cost_bbox=float(rng.choice([5.0, 1.0])),
               cost_giou=float(rng.choice([2.0, 1.0])), focal_alpha=float(rng.choice([0.25, 0.4])),
               focal_gamma=float(rng.choice([2.0, 2.0, 1.5, 1.0])))
@@ -45,7 +47,7 @@ while time.time() < t_end:
         for t in targets:
             if len(t["labels"]):
                 t["labels"] = torch.where(torch.rand(len(t["labels"]), device="cuda") < 0.3, t["labels"] - C, t["labels"])
-    sets = [synth.make_output_set(B, Q, C, gen, "cuda") for _ in range(S)]
+    sets = [synth.make_output_set(B, q, C, gen, "cuda") for q in widths]
     matcher = detr_amd.HungarianMatcher(**kw)
     got = matcher.match_many(sets, targets)
     calls += 1
@@ -66,5 +68,5 @@ while time.time() < t_end:
         other += 1 if ok else 0
         if not ok:
             bad += 1
-            print("MISMATCH", kw, "C", C, "Q", Q, "B", B, "image", b, "T", int(counts[b]), a, r, flush=True)
+            print("MISMATCH", kw, "C", C, "Q", widths, "set", s, "B", B, "image", b, "T", int(counts[b]), a, r, flush=True)
 print(f"{calls} calls, {same} images with the oracle's pairs, {other} with another optimum of equal cost, {bad} mismatches")
