@@ -975,6 +975,9 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
 }
 
 constexpr int NCOL_CLASSES[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 15, FAST_MAX_NCOL};
+// a kernel may take 4 KB of arguments: the output sets, the in-place target table and the 12 scalars / pointers
+// of lap_block_kernel have to fit
+static_assert(sizeof(DmSetArray) + sizeof(dm::FusedIn) + 12 * 8 <= 4096, "kernel-argument segment of lap_block_kernel");
 constexpr int FUSED_MAX_T = 256;      // the image's target records (48 bytes each) share LDS with the solver
 
 int ncol_class(int Q)
