@@ -1037,7 +1037,8 @@ int launch_wave_dyn(int ncol, const DmSetArray &arr, int n, const LapArgs &a, in
 // (NCOL, W) of the workgroup that solves problems with Q queries when P problems are in flight.
 // Few problems: as many wavefronts per problem as there are 64-column slices (latency);
 // many problems: fewer, fatter wavefronts so that the grid fits the chip in few rounds.
-void pick_shape(int Q, long long P, int *ncol, int *waves)
+// heavy: problems with many rows (max T > 32), whose launch takes as long as the chain of its heaviest problem.
+void pick_shape(int Q, long long P, bool heavy, int *ncol, int *waves)
 {
     const int need = (Q + 63) / 64;                    // 64-column slices
     long long w = need;
@@ -1046,16 +1047,24 @@ void pick_shape(int Q, long long P, int *ncol, int *waves)
     if (P * need > wave_budget) w = wave_budget / P;
     if (w > g_lap_max_waves) w = g_lap_max_waves;
     if (w < 1) w = 1;
-    // Few problems (every 64-column slice could have a wavefront of its own): more than twelve wavefronts per
-    // problem -- three per SIMD -- cost more than they bring, because a step takes as long as the wavefront that shares
-    // its SIMD with the most others (the SIMD serves the oldest first; measured: wavefronts 0-3 reach the step's
-    // barrier together, 4-7 some 220 cycles later, 8-11 some 470).  With 13 to 16 slices the problem gets twelve
-    // wavefronts and the slices left over are second columns of the first ones (Q = 900: 114 us for a problem with
-    // 100 targets against 127 us with 15 wavefronts and 123 us with 8 x 2 columns; Q = 1024: 70 / 76 / 73).  The
-    // wavefronts without a second column run the solver compiled for one (lap_block_kernel, `trimmed`).
-    if (g_lap_plain_shape != 1 && P * need <= wave_budget && g_lap_max_waves == 16) {
-        const int exact = g_lap_plain_shape > 1 ? std::min(g_lap_plain_shape, need)      // testing aid
-                                                : ((need > 12 && need <= 16) ? 12 : 0);
+    // 13 to 16 column slices (Q = 769 .. 1024): more than twelve wavefronts per problem -- three per SIMD -- cost more
+    // than they bring, because a step takes as long as the wavefront that shares its SIMD with the most others (the
+    // SIMD serves the oldest first; measured: wavefronts 0-3 reach the step's barrier together, 4-7 some 220 cycles
+    // later, 8-11 some 470).  The problem gets twelve wavefronts and the slices left over are second columns of the
+    // first ones (Q = 900: 114 us for a problem with 100 targets against 127 us with 15 wavefronts and 123 us with
+    // 8 x 2 columns; Q = 1024: 70 / 76 / 73) -- as long as the launch's wavefronts are resident together (twelve
+    // per problem up to 512 problems: 384 problems of Q = 900, T ~ 16: 54 us against 57 with eight and 60 with
+    // fifteen; 768 problems: 69 / 63 / 109) or the launch is as long as its heaviest problem anyway (T up to 100:
+    // 960 problems 124 against 130 us with eight, 1536 problems 135 / 140); eight wavefronts x 2 columns beyond that.
+    // The wavefronts without a second column run the solver compiled for one (lap_block_kernel, `trimmed`).
+    if (g_lap_plain_shape != 1 && g_lap_max_waves == 16) {
+        int exact = 0;
+        if (g_lap_plain_shape > 1) {      // testing aid
+            if (P * need <= wave_budget) exact = std::min(g_lap_plain_shape, need);
+        } else if (need > 12 && need <= 16 && !g_lap_wave_budget) {
+            if (P * 12 <= (heavy ? 18432 : 6144)) exact = 12;
+            else if (P * 8 <= 12288) exact = 8;
+        }
         if (exact > 0 && (need + exact - 1) / exact <= BLOCK_MAX_NCOL_WIDE) {
             *ncol = (need + exact - 1) / exact;
             *waves = exact;
@@ -1175,7 +1184,7 @@ static int make_plan(const DmSet *sets, int S, int B, int max_T, Plan &plan)
             }
         if (wide > 0) {
             int ncol = 0, waves = 0;
-            pick_shape(widest, (long long)wide * B, &ncol, &waves);
+            pick_shape(widest, (long long)wide * B, max_T > 32, &ncol, &waves);
             if (ncol <= BLOCK_MAX_NCOL_WIDE) fast_max_q = BLOCK_MAX_Q;
         }
     }
@@ -1208,7 +1217,7 @@ static int make_plan(const DmSet *sets, int S, int B, int max_T, Plan &plan)
         }
         const long long P = (long long)count * B;
         int ncol = 1, waves = 1;
-        if (distinct > 1) pick_shape(max_Q, P, &ncol, &waves);
+        if (distinct > 1) pick_shape(max_Q, P, max_T > 32, &ncol, &waves);
         // ... as long as all workgroups are resident at once (8192 wavefront slots on the chip)
         if (distinct > 1 && count <= DM_MAX_SETS_PER_LAUNCH && P * waves <= 8192 &&
             (max_Q <= FAST_MAX_Q || ncol <= BLOCK_MAX_NCOL_WIDE)) {
@@ -1240,7 +1249,7 @@ static int make_plan(const DmSet *sets, int S, int B, int max_T, Plan &plan)
         const long long slices = P * ((Q + 63) / 64);
         const bool use_block = g_lap_mode == 2 || Q > FAST_MAX_Q ||
                                (g_lap_mode == 0 && slices <= (max_T > 32 ? 98304 : 28672));
-        if (use_block) pick_shape(Q, P, &ncol, &waves);
+        if (use_block) pick_shape(Q, P, max_T > 32, &ncol, &waves);
         Launch l{use_block, ncol, waves, Q, Q, {}};
         for (int s = s0; s <= S; ++s) {
             if (s < S && !done[(size_t)s] && sets[s].Q == Q) {
