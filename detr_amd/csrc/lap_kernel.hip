@@ -1064,12 +1064,13 @@ void pick_shape(int Q, long long P, bool heavy, int *ncol, int *waves)
         } else if (need > 12 && need <= 16 && !g_lap_wave_budget) {
             if (P * 12 <= (heavy ? 18432 : 6144)) exact = 12;
             else if (P * 8 <= 12288) exact = 8;
-        } else if (need >= 9 && need <= 12 && w == need && P * need > 9216 && !heavy && !g_lap_wave_budget) {
+        } else if (need >= 5 && need <= 12 && need != 8 && w == need && P * need > 9216 && !heavy && !g_lap_wave_budget) {
             // One wavefront per slice only while (nearly) all of them are resident (8192 with one column per thread):
             // beyond that two columns per thread in about six wavefronts (Q = 600, T ~ 16: 960 problems 60 us against
             // 78 us with ten wavefronts, 1152 problems 74 / 88; Q = 768: 960 problems 67 / 75; up to 864 problems one
-            // wavefront per slice is as fast or faster: 79 / 82, and so it is with eight slices: Q = 512, 1152
-            // problems 63 / 68)
+            // wavefront per slice is as fast or faster: 79 / 82; Q = 300, 2240 problems: 66 against 84 us; Q = 384, 1800
+            // problems: 79 / 83).  Eight slices -- two wavefronts on every SIMD -- are best left alone (Q = 512: 1152
+            // problems 63 / 68, 1398 problems 68 / 72).
             exact = (int)std::max<long long>((need + 1) / 2, std::min<long long>(need, 6144 / P));
         }
         if (exact > 0 && (need + exact - 1) / exact <= BLOCK_MAX_NCOL_WIDE) {
