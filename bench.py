@@ -234,7 +234,10 @@ def launch_ranks(n):
             except subprocess.TimeoutExpired:
                 children[rank].kill()
     out = children[0].stdout.read() if children[0].stdout else ""
-    sys.stdout.write(out)
+    # stdout carries the JSON line only; anything a library of rank 0 printed there (gloo announces its
+    # connections on stdout) goes to stderr
+    for line in out.splitlines(keepends=True):
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
     sys.stdout.flush()
     if failed is not None:
         raise SystemExit(f"rank {failed[0]} exited with status {failed[1]}")

@@ -33,8 +33,8 @@ def _bench(*flags):
     """`python bench.py ...` on its own, as the driver runs it: no launcher around it."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags, "--steps", "5", "--warmup", "2"],
                          capture_output=True, text=True, timeout=300, check=True).stdout
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                  # rank 0 only
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out[:400]    # rank 0's JSON line and nothing else on stdout
     return json.loads(lines[0])
 
 
