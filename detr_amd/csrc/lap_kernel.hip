@@ -621,34 +621,54 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         constexpr int NC = decltype(columns_here)::value;
         int par = 0;
         unsigned scanned = 0;      // bit k: this thread's column k has been scanned (parked) in the current row
+        // This thread's entries of row i.  `fresh`: the first read of a row that is not resident in LDS (every row is
+        // read in full exactly once that way, as the row a search starts from): validated here.
+        auto read_row = [&](int i, float (&c)[NC], bool fresh) __attribute__((always_inline)) {
+            if (ALLRES || i < R) {
+                const float *row = crow + i * ls;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) c[k] = row[jc[k]];
+            } else {
+                const float *row = cg + (size_t)i * qs;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) c[k] = row[jc[k]];
+                if (!FUSED && fresh) {
+                    bool badrow = false;
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) badrow |= cost_is_invalid(c[k]);
+                    if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
+                }
+            }
+        };
+        // The first step of a row's search waits for no LDS read: the entries of the row it starts from were requested
+        // while the row before was being searched, the row's dual is still 0 and the last list position holds column 0
+        // at every row start.  (Requesting the reads of the later steps ahead as well -- right after the step before
+        // has picked its column, in front of its bookkeeping -- measured slower.)
+        float cnext[NC];
+        read_row(0, cnext, true);
         for (int cur = 0; cur < nr; ++cur) {
             double min_val = 0.0;
             int i = cur, n = nc, sink = -1;
+            double ui = 0.0;                              // u[cur]: untouched before its own row
+            int jl_read = 0;                              // column at the last list position: 0 at a row start
+            float c[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) c[k] = cnext[k];
+            if (cur + 1 < nr) read_row(cur + 1, cnext, true);
 
             // Every step parks one column or ends the row; when no column is left every candidate is +inf,
             // which ends the loop as infeasible: two exits only.
+            bool first_step = true;
             for (;;) {
 #ifdef DM_LAP_STAMPS
                 asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
 #endif
-                const double ui = u[i];
-                const int jl_read = remaining[n - 1];     // column at the last list position
-                float c[NC];
-                if (ALLRES || i < R) {
-                    const float *row = crow + i * ls;
-#pragma unroll
-                    for (int k = 0; k < NC; ++k) c[k] = row[jc[k]];
-                } else {
-                    const float *row = cg + (size_t)i * qs;
-#pragma unroll
-                    for (int k = 0; k < NC; ++k) c[k] = row[jc[k]];
-                    if (!FUSED && i == cur) {     // the only full read of a row that is not resident: validate it here
-                        bool badrow = false;
-#pragma unroll
-                        for (int k = 0; k < NC; ++k) badrow |= cost_is_invalid(c[k]);
-                        if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
-                    }
+                if (!first_step) {      // a row reached through an assigned column
+                    ui = u[i];
+                    jl_read = remaining[n - 1];
+                    read_row(i, c, false);
                 }
+                first_step = false;
                 DM_STAMP(0)
                 double lmin = INF;
 #pragma unroll
@@ -723,6 +743,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                 const int jl = __builtin_amdgcn_readfirstlane(jl_read);
                 if (lane == 0) remaining[pw] = jl;
                 --n;
+                i = rw;
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     const int j = tid + BS * k;
@@ -734,7 +755,6 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
                     }
                 }
                 DM_STAMP(4)
-                i = rw;
             }
             if (sink < 0) {      // ran out of columns without reaching an unassigned one
                 if (tid == 0) dm::raise_status(status, DM_ST_INFEASIBLE);
