@@ -229,9 +229,39 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
     st_c1 = __builtin_amdgcn_s_memtime();
 #endif
 
+    // This lane's entries of row i.  `fresh`: the first read of a row that is not resident in LDS (every row is
+    // read in full exactly once that way, as the row a search starts from): validated here.
+    auto read_row = [&](int i, float (&c)[NCOL], bool fresh) __attribute__((always_inline)) {
+        if (i < R) {
+            const float *row = crow + i * ls;
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+        } else {
+            const float *row = cg + (size_t)i * qs;
+#pragma unroll
+            for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
+            if (fresh) {
+                bool badrow = false;
+#pragma unroll
+                for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
+                if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
+            }
+        }
+    };
+    // The first step of a row's search waits for no read: its row was requested while the row before was being
+    // searched, its dual is still 0 and the last list position holds column 0 at every row start.
+    float cnext[NCOL];
+    read_row(0, cnext, true);
     for (int cur = 0; cur < nr; ++cur) {
         double min_val = 0.0;
         int i = cur, n = nc, sink = -1;
+        double ui = 0.0;
+        int jl = 0;
+        float c[NCOL];
+#pragma unroll
+        for (int k = 0; k < NCOL; ++k) c[k] = cnext[k];
+        if (cur + 1 < nr) read_row(cur + 1, cnext, true);
+        bool first_step = true;
 
         // every step parks one column or ends the row; with no column left every candidate is +inf,
         // which ends the loop as infeasible (sink stays -1): two exits only
@@ -239,24 +269,12 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
 #ifdef DM_LAP_STAMPS
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");
 #endif
-            const double ui = u[i];
-            const int jl = __builtin_amdgcn_readfirstlane(remaining[n - 1]);   // column at the last list position
-            float c[NCOL];
-            if (i < R) {
-                const float *row = crow + i * ls;
-#pragma unroll
-                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
-            } else {
-                const float *row = cg + (size_t)i * qs;
-#pragma unroll
-                for (int k = 0; k < NCOL; ++k) c[k] = row[jc[k]];
-                if (i == cur) {     // the only full read of a row that is not resident: validate it here
-                    bool badrow = false;
-#pragma unroll
-                    for (int k = 0; k < NCOL; ++k) badrow |= cost_is_invalid(c[k]);
-                    if (badrow) dm::raise_status(status, DM_ST_INVALID_COST);
-                }
+            if (!first_step) {      // a row reached through an assigned column
+                ui = u[i];
+                jl = __builtin_amdgcn_readfirstlane(remaining[n - 1]);   // column at the last list position
+                read_row(i, c, false);
             }
+            first_step = false;
             DM_STAMP(0)
             double lmin = INF;
 #pragma unroll
