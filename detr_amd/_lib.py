@@ -42,7 +42,7 @@ class DmParams(ctypes.Structure):
 
 #: every symbol include/detr_match.h declares
 EXPORTS = ["dm_pack_targets", "dm_abi_version", "dm_strerror", "dm_last_hip_error", "dm_device_count",
-           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_targets_f32", "dm_match_noalloc_f32",
+           "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_targets_f32", "dm_match_noalloc_f32", "dm_noalloc_scratch",
            "dm_profile_enable", "dm_profile_read", "dm_match_plan",
            "dm_debug_set_knob",
            "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
@@ -85,6 +85,8 @@ def _load():
                                          i64p, i64p, i64p, vp, vp, ctypes.POINTER(ctypes.c_int)]
     lib.dm_match_noalloc_f32.restype = ctypes.c_int
     lib.dm_match_noalloc_f32.argtypes = [setp, i32, i32, i32, vp, vp, vp, vp, i32, i32, prmp, i64p, i64p, vp, vp]
+    lib.dm_noalloc_scratch.restype = ctypes.c_int
+    lib.dm_noalloc_scratch.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
     isetp = ctypes.POINTER(DmIndexSet)
     lib.dm_pair_loss_f32.restype = ctypes.c_int
     lib.dm_pair_loss_f32.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, vp, vp, vp]

@@ -222,9 +222,10 @@ extern "C" int dm_match_f32(const DmSet *sets, int S, int B, int C, const int64_
 }
 
 // ---- the entry point that allocates nothing ----------------------------------------------------
-// The cost blocks that travel from the cost kernel to the assignment kernel live in a fixed array of
-// device memory that belongs to the library (one copy per GPU, held until the process ends) instead
-// of a workspace the caller allocates.
+// What dm_match_fused_f32 keeps in its caller's workspace -- the cost blocks that travel from the cost kernel
+// to the assignment kernel (C > 4, sets with T >= Q) and the rows of a block that a fused assignment workgroup
+// cannot hold in LDS -- lives in a fixed array of device memory that belongs to the library (one copy per GPU,
+// held until the process ends).
 namespace {
 __device__ __align__(256) float scratch[DM_NOALLOC_MAX_COST_FLOATS];
 
@@ -252,6 +253,13 @@ int scratch_address(float **out)
     return DM_OK;
 }
 }  // namespace
+
+extern "C" int dm_noalloc_scratch(float **ptr, uint64_t *floats)
+{
+    if (!ptr || !floats) return DM_E_INVALID_ARG;
+    *floats = DM_NOALLOC_MAX_COST_FLOATS;
+    return scratch_address(ptr);
+}
 
 extern "C" int dm_match_noalloc_f32(const DmSet *sets, int S, int B, int C, const int64_t *tgt_labels,
                                     const float *tgt_boxes, const int32_t *tgt_off, const int32_t *order, int max_T,

@@ -186,22 +186,30 @@ int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, const uint64_t 
 
 /*
  * dm_match_f32 for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  The cost
- * blocks between the two kernels live in a fixed array of DM_NOALLOC_MAX_COST_FLOATS floats (32 MiB)
- * that the library holds on every GPU it runs on until the process ends, so there is no `cost`
- * argument; the call itself calls no hipMalloc / hipFree or other allocating routine.
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  What dm_match_f32
+ * keeps in its `cost` workspace -- the cost blocks on their way from the cost kernel to the assignment kernel
+ * (C > 4, sets that can meet an image with T >= Q) and, where the assignment workgroups compute their own
+ * blocks, the rows that do not fit in LDS -- lives in a fixed array of DM_NOALLOC_MAX_COST_FLOATS floats (32 MiB)
+ * that the library holds on every GPU it runs on until the process ends, so there is no `cost` argument; the
+ * call itself calls no hipMalloc / hipFree or other allocating routine.
  *   M   host-known total number of targets, tgt_off[B]
  * sets[s].cost_off / q_stride place set s inside that array as they do inside `cost` above: every set's
  * region [cost_off, cost_off + M * q_stride) must end at or before DM_NOALLOC_MAX_COST_FLOATS, else
  * DM_E_UNSUPPORTED (nothing is launched).  All calls on one GPU share the array: calls that overlap in time
  * on the same GPU (two streams, two threads) race; serialise them.  Nothing in it needs clearing between
- * calls (the assignment kernel reads only entries the cost kernel of the same call wrote).
+ * calls: a kernel reads only entries that a kernel (or the same thread) of the same call has written before,
+ * so what an earlier call left behind is never seen.
  */
 #define DM_NOALLOC_MAX_COST_FLOATS (8u << 20)
 int dm_match_noalloc_f32(const DmSet *sets, int S, int B, int C,
                          const int64_t *tgt_labels, const float *tgt_boxes, const int32_t *tgt_off,
                          const int32_t *order, int max_T, int M, const DmParams *params,
                          int64_t *src_out, int64_t *tgt_out, int32_t *status, void *stream);
+/*
+ * Testing aid (no counterpart in the reference): the address of that array on the current GPU and its length
+ * in floats, so that a test can fill it with a marker before a call and read back what the call left in it.
+ */
+int dm_noalloc_scratch(float **ptr, uint64_t *floats);
 
 /*
  * ---- Consumers of the indices (the criterion's first steps after the matcher) ----------------

@@ -257,6 +257,26 @@ def test_workload_cfg4_reduced_batch():
     assert exact >= 0.99 * total
 
 
+def test_workload_cfg4_full_vs_oracle():
+    """cfg4 at the size it is quoted at (B=256, Q=900, C=91, heavy-tail T, 1536 problems): every problem against
+    scipy on the GPU's own cost, every cost block and every index pair against the C oracle (matcher.py:59-95)."""
+    exact, total = _check_workload("cfg4")
+    assert total == 6 * 256 - _empty_problems("cfg4") and exact >= 0.99 * total
+
+
+def test_workload_cfg5_full_vs_oracle():
+    """cfg5 on one GPU (B=1024, 12 sets of Q=600, 12 288 problems), problem by problem like cfg4 above."""
+    exact, total = _check_workload("cfg5")
+    assert total == 12 * 1024 - _empty_problems("cfg5") and exact >= 0.99 * total
+
+
+def _empty_problems(name):
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cpu")
+    return len(sets) * sum(1 for t in targets if len(t["labels"]) == 0)
+
+
 def test_workload_cfg4_full_size_properties():
     """Full cfg4 (B=256, Q=900, C=91, heavy-tail T): permutation validity everywhere,
     scipy equality on a sample of problems."""
