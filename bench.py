@@ -6,8 +6,11 @@
 A "step" is one pass of the matcher over one batch: all Hungarian-matched output sets of
 one training step (cfg2: B=64 images, 6 decoder-layer sets, Q=600, ~16 targets per image,
 focal class cost) from "predictions and targets resident in HBM" to "CPU int64 index
-tensors in the caller's hands" -- i.e. packing the targets, the cost kernel, the
-assignment kernel, the device-to-host copy of the indices and the stream synchronisation.
+tensors in the caller's hands" -- one `match_many` call: the target tensors checked and their
+pointers collected, the step's kernel(s) (at C <= 4 ONE kernel: every assignment workgroup
+computes its own cost block in LDS, reads the targets where they are and stores the indices
+into the pinned host tensor the returned tuples are views of; at C > 4 a pack launch, the cost
+kernel and the assignment kernel), the completion event, the per-image CPU tuples.
 With N > 1 there is one process per GPU: started by torch.distributed.run (RANK / LOCAL_RANK /
 WORLD_SIZE in the environment), or -- when `python bench.py --gpus N` is run on its own -- by
 this script, which starts its N ranks as child processes before it touches a GPU.  Every rank
@@ -19,6 +22,8 @@ have been enqueued).
 Prints one JSON line: whole-job matched images/s, plus
   roofline      cost kernel on this run's inputs: algorithmic bytes per launch / HIP-event time per
                 launch (back-to-back launches in a pass of its own), vs 8 TB/s
+  per_layer_calls  the same step as the reference's unmodified criteria drive it: one matcher(output, targets)
+                call per output set (detr/loss.py:164-169), each returning its CPU tuples before the next starts
   cpu_baseline  the reference's CPU formulation (torch ops on the whole batch + scipy per
                 image, restated in oracle/torch_pipeline.py) timed on this host, rank 0, N=1.
 """
@@ -198,6 +203,74 @@ def flat_path(matcher, sets, targets, device, steps):
     matcher.check_status()
     return {"value": len(targets) * steps / elapsed, "unit": "images/s", "ms_per_step": 1e3 * elapsed / steps,
             "what": "match_flat on pre-packed targets: device-resident flat indices, one sync after all steps"}
+
+
+def per_layer_calls(matcher, sets, fresh, device, steps, prefetch=False):
+    """The step as the reference's criteria drive it when only the import is swapped: one
+    `matcher(output, targets)` call per output set, in a Python loop, every call handing its CPU tuples back
+    before the next one starts (/root/reference/models/detr/loss.py:164-169; with a first-stage set
+    /root/reference/models/dino_detr/loss.py:165-199).  The targets are new tensor objects at every step and the same
+    objects within a step, as in that loop.  A kernel-event pass of its own gives the GPU share.
+    `prefetch`: the same loop behind what the forward pre-hook of detr_amd.criterion.attach does when the criterion
+    is called -- all sets matched in one batched call, the loop's calls find their results waiting."""
+    import detr_amd
+
+    if prefetch:
+        def step(turn):
+            targets = fresh[turn & 3]
+            matcher.prefetch(sets, targets)
+            for o in sets:
+                indices = matcher(o, targets)       # the loop keeps one set's indices at a time (loss.py:169)
+            matcher.clear_prefetched()
+            return indices
+
+        for k in range(10):
+            step(k)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            held = step(k)
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        del held
+        return {"value": len(fresh[0]) * steps / elapsed, "unit": "images/s", "ms_per_step": 1e3 * elapsed / steps,
+                "calls_per_step": len(sets),
+                "what": "the same loop of per-set calls after detr_amd.criterion.attach(criterion): a forward pre-hook "
+                        "matches all sets in one match_many call, the loop's calls are served from it"}
+
+    def step(turn):
+        targets = fresh[turn & 3]
+        for o in sets:
+            indices = matcher(o, targets)           # the loop keeps one set's indices at a time (loss.py:169)
+        return indices
+
+    for k in range(10):
+        step(k)
+    cost_ms, lap_ms = ctypes.c_float(), ctypes.c_float()
+    gpu_ms = 0.0
+    detr_amd.lib.dm_profile_enable(1)
+    try:
+        for k in range(max(steps // 4, 10)):
+            targets = fresh[k & 3]
+            for o in sets:
+                matcher(o, targets)
+                detr_amd.lib.dm_profile_read(ctypes.byref(cost_ms), ctypes.byref(lap_ms))
+                gpu_ms += cost_ms.value + lap_ms.value
+    finally:
+        detr_amd.lib.dm_profile_enable(0)
+    gpu_ms /= max(steps // 4, 10)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        held = step(k)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    del held
+    return {"value": len(fresh[0]) * steps / elapsed, "unit": "images/s", "ms_per_step": 1e3 * elapsed / steps,
+            "calls_per_step": len(sets), "ms_per_call": 1e3 * elapsed / steps / len(sets),
+            "kernel_ms_per_step": gpu_ms, "host_and_latency_ms_per_step": 1e3 * elapsed / steps - gpu_ms,
+            "what": "for output in sets: matcher(output, targets) -- the reference's criterion loop with only the "
+                    "import swapped; every call returns its CPU tuples before the next starts"}
 
 
 def launch_ranks(n):
@@ -451,6 +524,8 @@ def main():
         }
         if world == 1:
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
+            record["per_layer_calls"] = per_layer_calls(matcher, sets, fresh, device, args.steps)
+            record["per_layer_calls_prefetched"] = per_layer_calls(matcher, sets, fresh, device, args.steps, prefetch=True)
         if world == 1 and not args.no_stress:
             record["roofline_stress"] = stress_roofline(device)
         if world == 1 and not args.no_cpu_baseline:

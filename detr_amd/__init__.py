@@ -7,6 +7,6 @@ the work is done by two hand-written HIP kernels in ``libdetr_match.so`` (C ABI 
 from ._lib import LIB_PATH, lib  # noqa: F401  (fails loudly when the extension is missing)
 from .matcher import FlatMatches, HungarianMatcher, PackedTargets  # noqa: F401
 from .lsap import batched_linear_sum_assignment  # noqa: F401
-from . import aux_assign, dist, losses, synth  # noqa: F401
+from . import aux_assign, criterion, dist, losses, synth  # noqa: F401
 
-__all__ = ["HungarianMatcher", "PackedTargets", "FlatMatches", "batched_linear_sum_assignment", "aux_assign", "dist", "losses", "synth", "LIB_PATH"]
+__all__ = ["HungarianMatcher", "PackedTargets", "FlatMatches", "batched_linear_sum_assignment", "aux_assign", "criterion", "dist", "losses", "synth", "LIB_PATH"]

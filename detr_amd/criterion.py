@@ -1,0 +1,88 @@
+"""One line that gives an unmodified criterion the batched matching call.
+
+The reference's criteria walk ``outputs['model']`` (one dict per decoder layer), for the two-stage
+models also ``outputs['first_stage']``, and call ``self.matcher(output, targets)`` once per dict
+(/root/reference/models/detr/loss.py:160-183, dino_detr/loss.py:162-203, co_detr/loss.py:195-246; the
+denoising groups 'cdn' / 'noised' bring their indices with them and never reach the matcher).  Each of
+those calls is a kernel that takes as long as the heaviest image of the batch, plus a completion round
+trip -- six or seven times per step.
+
+``attach(criterion)`` swaps ``criterion.matcher`` for a :class:`detr_amd.HungarianMatcher` with the same
+hyper-parameters and registers a forward pre-hook on the criterion: when the criterion is called, the hook
+sees the whole ``outputs`` dict, matches all the sets the loop is going to ask for in ONE
+``match_many`` call (``HungarianMatcher.prefetch``), and the loop's per-set calls find their result
+waiting.  The criterion's code stays as it is; a set the hook did not foresee is matched on the spot.
+"""
+from typing import Iterable, Sequence
+
+import torch
+
+from .matcher import HungarianMatcher
+
+#: the keys of `outputs` whose sets the reference's criteria hand to the Hungarian matcher
+MATCHED_KEYS = ("model", "first_stage")
+
+
+def matcher_like(other) -> HungarianMatcher:
+    """A detr_amd matcher with the hyper-parameters of `other` (the reference's matcher object, or anything
+    with the same attributes: models/matcher.py:29-36)."""
+    if isinstance(other, HungarianMatcher):
+        return other
+    return HungarianMatcher(cls_loss=other.cls_loss, cost_class=other.cost_class, cost_bbox=other.cost_bbox,
+                            cost_giou=other.cost_giou, focal_alpha=other.focal_alpha, focal_gamma=other.focal_gamma)
+
+
+def sets_the_loop_will_match(outputs: dict, keys: Iterable[str] = MATCHED_KEYS, last_only: bool = False):
+    """The output dicts a criterion's loop hands to the matcher, in its order: every dict of ``outputs[key]``
+    (only the last one with `last_only`, the reference's ``aux_flag = False``: `_outputs[-1:]`)."""
+    found = []
+    for key in keys:
+        group = outputs.get(key) if isinstance(outputs, dict) else None
+        if not group:
+            continue
+        if isinstance(group, dict):
+            group = [group]
+        if last_only:
+            group = group[-1:]
+        for o in group:
+            if isinstance(o, dict) and "pred_logits" in o and "pred_boxes" in o:
+                found.append(o)
+    return found
+
+
+def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS) -> HungarianMatcher:
+    """Make `criterion` (an instance of one of the reference's Criterion classes, or anything that keeps its
+    matcher in ``.matcher`` and is called as ``criterion(outputs, targets)``) use the gfx950 matcher, all sets
+    of a step matched in one call.  Returns the matcher.  Calling it twice on one criterion is harmless."""
+    matcher = matcher_like(criterion.matcher)
+    criterion.matcher = matcher
+    if getattr(criterion, "_detr_amd_hooks", None) is not None:
+        return matcher
+
+    def before(module, args, kwargs):
+        outputs = args[0] if args else kwargs.get("outputs")
+        targets = args[1] if len(args) > 1 else kwargs.get("targets")
+        m = module.matcher
+        if not isinstance(m, HungarianMatcher) or outputs is None or targets is None:
+            return None
+        m.prefetch(sets_the_loop_will_match(outputs, keys, last_only=not getattr(module, "aux_flag", True)), targets)
+        return None
+
+    def after(module, args, kwargs, result):
+        m = module.matcher
+        if isinstance(m, HungarianMatcher):
+            m.clear_prefetched()
+        return None
+
+    criterion._detr_amd_hooks = (criterion.register_forward_pre_hook(before, with_kwargs=True),
+                                 criterion.register_forward_hook(after, with_kwargs=True, always_call=True))
+    return matcher
+
+
+def detach(criterion: torch.nn.Module) -> None:
+    """Remove the hooks `attach` registered (the matcher stays)."""
+    hooks = getattr(criterion, "_detr_amd_hooks", None)
+    if hooks is not None:
+        for h in hooks:
+            h.remove()
+        criterion._detr_amd_hooks = None

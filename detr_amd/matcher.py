@@ -8,7 +8,11 @@ list of ``(index_i, index_j)`` CPU int64 tensors, one per image, with
 On top of that, ``match_many`` matches every Hungarian-matched output set of a
 training step (the decoder layers the criteria loop over, e.g.
 /root/reference/models/dino_detr/loss.py:165-199, plus the two-stage encoder head)
-in one cost launch, one assignment launch and one device-to-host copy.
+in one call: with up to four logits per query ONE kernel launch (every assignment
+workgroup computes its own cost block in LDS and stores its indices straight into the
+pinned host tensor the returned tuples are views of), with more classes one cost launch
+and one assignment launch; completion is one event either way.  ``prefetch`` does that
+ahead of a loop of per-set calls (see detr_amd/criterion.py).
 
 There is no CPU path: inputs must live on a GPU and the HIP library must be built.
 """
@@ -377,6 +381,7 @@ class HungarianMatcher(torch.nn.Module):
         self._buffers = {}
         self._packed = None
         self._params_cache = None
+        self._prefetched = None
 
     def __getstate__(self):
         # per-device events and buffers, the packed targets and the last status view belong to this
@@ -386,12 +391,13 @@ class HungarianMatcher(torch.nn.Module):
         state["_buffers"] = {}
         state["_packed"] = None
         state["_params_cache"] = None
+        state["_prefetched"] = None
         state["last_status"] = None
         return state
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None),
+        for name, value in (("_events", {}), ("_buffers", {}), ("_packed", None), ("_params_cache", None), ("_prefetched", None),
                             ("through_ops", False), ("indices_to_host", True)):
             self.__dict__.setdefault(name, value)
 
@@ -416,10 +422,49 @@ class HungarianMatcher(torch.nn.Module):
             cached = self._params_cache = (key, params, ctypes.byref(params), ctypes.addressof(params))
         return cached[2]
 
-    @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets) -> Indices:
-        """One output set; same contract as the reference's forward (matcher.py:38-95)."""
+        """One output set; same contract as the reference's forward (matcher.py:38-95).  (No gradient is
+        recorded: match_many runs under torch.no_grad.)"""
+        ahead = self.__dict__.get("_prefetched")
+        if ahead:
+            hit = ahead.get(id(outputs))
+            if hit is not None:
+                found = self._prefetch_hit(hit, outputs, targets)
+                if found is not None:
+                    return found
         return self.match_many([outputs], targets)[0]
+
+    def prefetch(self, outputs_list: Sequence[Dict[str, torch.Tensor]], targets) -> None:
+        """Match all of `outputs_list` now, in one `match_many` call, and hand the results out when `forward` is
+        called with one of these very output dicts and these very targets (same objects, tensors unchanged since):
+        what lets a criterion that calls the matcher once per decoder layer
+        (/root/reference/models/detr/loss.py:164-169) run at the speed of one batched call without a change to
+        its loop.  A call with anything else is matched on the spot as usual.  `clear_prefetched` drops the
+        results (and the references to the predictions they are keyed by)."""
+        state = self.__dict__
+        state["_prefetched"] = None
+        outputs_list = list(outputs_list)
+        if not outputs_list:
+            return
+        results = self.match_many(outputs_list, targets)
+        table = {}
+        for o, r in zip(outputs_list, results):
+            l, x = o["pred_logits"], o["pred_boxes"]
+            table[id(o)] = (o, l, x, l._version, x._version, targets, r)
+        state["_prefetched"] = table
+
+    def clear_prefetched(self) -> None:
+        self.__dict__["_prefetched"] = None
+
+    def _prefetch_hit(self, hit, outputs, targets):
+        o, l, x, lv, xv, tg, result = hit
+        if o is not outputs or outputs["pred_logits"] is not l or outputs["pred_boxes"] is not x \
+                or l._version != lv or x._version != xv:
+            return None
+        packed = self._packed
+        if targets is not tg or packed is None or not packed.same_targets(targets):
+            return None
+        return result
 
     @staticmethod
     def _prepare_sets(outputs_list, batch: int):

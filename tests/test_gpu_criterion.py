@@ -1,0 +1,123 @@
+"""detr_amd.criterion.attach: an unmodified criterion loop (one matcher call per output set, as in
+/root/reference/models/detr/loss.py:160-183 and dino_detr/loss.py:162-203) gets all its sets matched in one
+batched call made by a forward pre-hook; the loop's own calls find their results waiting."""
+import types
+
+import pytest
+import torch
+
+
+class LoopCriterion(torch.nn.Module):
+    """The calling pattern of the reference's criteria, nothing else: walks the decoder-layer sets, skips the
+    denoising sets (they bring their indices), then the first-stage sets; keeps what the matcher returned."""
+
+    def __init__(self, matcher, aux_flag=True):
+        super().__init__()
+        self.matcher = matcher
+        self.aux_flag = aux_flag
+        self.seen = []
+
+    def forward(self, outputs, targets):
+        self.seen = []
+        for key in ("model", "cdn"):
+            group = outputs.get(key, [])
+            if not self.aux_flag:
+                group = group[-1:]
+            for output in group:
+                if key == "cdn":
+                    continue
+                self.seen.append(self.matcher(output, targets))
+        for output in outputs.get("first_stage", []):
+            self.seen.append(self.matcher(output, targets))
+        return len(self.seen)
+
+
+def test_the_sets_a_loop_will_match_cpu():
+    from detr_amd.criterion import matcher_like, sets_the_loop_will_match
+
+    mk = lambda: {"pred_logits": torch.zeros(1, 2, 2), "pred_boxes": torch.zeros(1, 2, 4)}
+    outputs = {"model": [mk(), mk(), mk()], "cdn": [mk()], "first_stage": [mk()], "cdn_indices": [], "aux": {"atss": [mk()]}}
+    found = sets_the_loop_will_match(outputs)
+    assert [id(o) for o in found] == [id(o) for o in outputs["model"] + outputs["first_stage"]]
+    last = sets_the_loop_will_match(outputs, last_only=True)
+    assert [id(o) for o in last] == [id(outputs["model"][-1]), id(outputs["first_stage"][-1])]
+    assert sets_the_loop_will_match({"model": []}) == []
+    ref = types.SimpleNamespace(cls_loss="focal", cost_class=2.0, cost_bbox=5.0, cost_giou=2.0, focal_alpha=0.3,
+                                focal_gamma=1.5)
+    m = matcher_like(ref)
+    assert (m.cls_loss, m.cost_class, m.cost_bbox, m.cost_giou, m.focal_alpha, m.focal_gamma) == \
+        ("focal", 2.0, 5.0, 2.0, 0.3, 1.5)
+    assert matcher_like(m) is m
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for (a0, a1), (b0, b1) in zip(a, b):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("aux_flag", [True, False])
+def test_attached_criterion_matches_once_per_step(aux_flag):
+    import detr_amd
+    from detr_amd import synth
+    from detr_amd.criterion import attach, detach
+
+    wl, sets, targets = synth.make_workload("cfg3_hw", device="cuda", batch=8)
+    outputs = {"model": sets[:6], "cdn": [dict(sets[0])], "first_stage": sets[6:], "cdn_indices": None}
+    plain = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    want = [plain(o, targets) for o in (sets[:6] if aux_flag else sets[5:6]) + sets[6:]]
+    want = [[(a.clone(), b.clone()) for a, b in per] for per in want]
+
+    ref_like = types.SimpleNamespace(**wl.matcher_kwargs)       # what the reference's matcher object exposes
+    crit = LoopCriterion(ref_like, aux_flag=aux_flag)
+    matcher = attach(crit)
+    assert crit.matcher is matcher and attach(crit) is matcher
+    calls = []
+    inner = matcher.match_many
+    matcher.match_many = lambda *a, **k: (calls.append(len(a[0])), inner(*a, **k))[1]
+    for step in range(3):
+        fresh = [{k: v[:] for k, v in t.items()} for t in targets]
+        n = crit(outputs, fresh)
+        assert n == len(want)
+        for got, ref in zip(crit.seen, want):
+            _same(got, ref)
+    assert calls == [len(want)] * 3          # one batched call per step, none from the loop
+    assert matcher._prefetched is None       # dropped after the criterion returned
+
+    # a set the hook could not foresee, and targets it was not given, are matched on the spot
+    calls.clear()
+    matcher.prefetch(sets[:2], targets)
+    _same(matcher(sets[0], targets), want[0] if aux_flag else plain(sets[0], targets))
+    assert calls == [2]
+    other = dict(sets[0])
+    matcher(other, targets)
+    assert calls == [2, 1]
+    matcher(sets[1], [{k: v[:] for k, v in t.items()} for t in targets])
+    assert calls == [2, 1, 1]
+    # predictions changed in place after the prefetch: not served from it
+    matcher.prefetch(sets[:2], targets)
+    sets[1]["pred_boxes"].mul_(1.0)
+    matcher(sets[1], targets)
+    assert calls == [2, 1, 1, 2, 1]
+    detach(crit)
+    matcher.clear_prefetched()
+    calls.clear()
+    crit(outputs, targets)
+    assert calls == [1] * len(want)
+
+
+@pytest.mark.gpu
+def test_attached_criterion_raises_what_the_loop_would():
+    import detr_amd
+    from detr_amd import synth
+    from detr_amd.criterion import attach
+
+    wl, sets, targets = synth.make_workload("cfg2", device="cuda", batch=4)
+    sets = sets[:3]
+    sets[2]["pred_boxes"][1, 5, 2] = float("nan")
+    crit = LoopCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs))
+    attach(crit)
+    with pytest.raises(AssertionError):
+        crit({"model": sets}, targets)
+    assert crit.matcher._prefetched is None
