@@ -36,16 +36,22 @@ HELPER = os.path.join(PKG, "_index_views.so")
 def build_helper(force=False, verbose=False):
     """The host-side helper module detr_amd._index_views (bulk creation of the per-image index views;
     plain C++ against the torch headers, no GPU code)."""
-    if not force and os.path.exists(HELPER) and os.path.getmtime(HELPER) >= os.path.getmtime(HELPER_SRC):
-        return HELPER
     import sysconfig
 
     import torch
     from torch.utils import cpp_extension
 
+    # the helper reaches into tensor internals: it is built for exactly one torch version and says which
+    stamp = ("detr_amd_index_views built for torch %s;" % torch.__version__).encode()
+    if not force and os.path.exists(HELPER) and os.path.getmtime(HELPER) >= os.path.getmtime(HELPER_SRC):
+        with open(HELPER, "rb") as f:
+            if stamp in f.read():
+                return HELPER
+
     libdir = cpp_extension.library_paths()[0]
     cmd = ["g++", "-O2", "-shared", "-fPIC", "-std=c++17",
-           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
+           '-DDM_BUILT_FOR_TORCH="%s"' % torch.__version__]
     for inc in cpp_extension.include_paths() + [sysconfig.get_paths()["include"]]:
         cmd += ["-I", inc]
     cmd += [HELPER_SRC, "-o", HELPER, "-L", libdir, "-ltorch_python", "-ltorch", "-ltorch_cpu", "-lc10",

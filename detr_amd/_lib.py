@@ -21,7 +21,7 @@ NOALLOC_MAX_COST_FLOATS = 8 << 20
 
 OK, E_INVALID_ARG, E_LAUNCH, E_UNSUPPORTED = 0, -1, -2, -3
 NEED_BUFFERS = 1     # dm_match_targets_f32 without pack buffers: nothing launched
-ST_LABEL_RANGE, ST_DEGENERATE_BOX, ST_INVALID_COST, ST_INFEASIBLE = 1, 2, 4, 8
+ST_LABEL_RANGE, ST_DEGENERATE_BOX, ST_INVALID_COST, ST_INFEASIBLE, ST_BAD_SIZES = 1, 2, 4, 8, 16
 
 
 class DmSet(ctypes.Structure):

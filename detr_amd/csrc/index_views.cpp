@@ -29,9 +29,20 @@
 // launch_targets is the usual step's host side in one call: output scan, pinned result tensor, the library's
 // entry point (through its address).
 // No GPU code here; the kernels are in the .hip files.
+//
+// Contract.  The pools are process-global and shared by every matcher object; every function here runs from
+// start to end under the interpreter lock (none releases it), so calls from several Python threads are
+// serialised and each sees the pools in a consistent state.  An object is re-pointed only when the pool (and,
+// for a recycled result, its tuple) holds the ONLY references to it -- the reference counts are read under
+// that same lock -- so a result somebody still holds, in any thread, through any matcher, is never changed;
+// what interleaving callers lose is only the recycling (their objects are still held when their turn comes
+// round again, fresh ones take their place).  The functions reach into tensor internals that are not a
+// stable interface: the module records the torch version it was compiled against (`built_for_torch`) and the
+// Python code refuses to use it under any other.
 #include <Python.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include <ATen/ATen.h>
@@ -500,11 +511,28 @@ PyModuleDef module = {PyModuleDef_HEAD_INIT, "_index_views", "bulk creation of i
 
 }  // namespace
 
+#ifndef DM_BUILT_FOR_TORCH
+#define DM_BUILT_FOR_TORCH "unknown"
+#endif
+// (also found by build_ext.py in the file's bytes: a library built for another torch is rebuilt)
+extern "C" const char dm_index_views_stamp[] = "detr_amd_index_views built for torch " DM_BUILT_FOR_TORCH ";";
+
 PyMODINIT_FUNC PyInit__index_views(void)
 {
+    // compiled against one CPython's object layout (reference counts, weak-reference lists, tuple items)
+    int major = 0, minor = 0;
+    if (sscanf(Py_GetVersion(), "%d.%d", &major, &minor) != 2 || major != PY_MAJOR_VERSION || minor != PY_MINOR_VERSION) {
+        PyErr_Format(PyExc_ImportError, "_index_views was built for Python %d.%d", PY_MAJOR_VERSION, PY_MINOR_VERSION);
+        return nullptr;
+    }
     g_key_labels = PyUnicode_InternFromString("labels");
     g_key_boxes = PyUnicode_InternFromString("boxes");
     g_key_logits = PyUnicode_InternFromString("pred_logits");
     g_key_pboxes = PyUnicode_InternFromString("pred_boxes");
-    return PyModule_Create(&module);
+    PyObject *m = PyModule_Create(&module);
+    if (m && PyModule_AddStringConstant(m, "built_for_torch", DM_BUILT_FOR_TORCH) < 0) {
+        Py_DECREF(m);
+        return nullptr;
+    }
+    return m;
 }

@@ -147,6 +147,10 @@ __global__ __launch_bounds__(64) void lap_wave_kernel(const DmSetArray sets, con
     const int t0 = tgt_off[b];
     const int nr = tgt_off[b + 1] - t0;   // rows = targets
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
+    if (nr > t_cap || nr < 0) {      // more targets than the caller's max_T said: the LDS arrays are sized by it
+        if (lane == 0) dm::raise_status(status, DM_ST_BAD_SIZES);
+        return;
+    }
 #ifdef DM_LAP_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_c1 = 0;
@@ -543,6 +547,10 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         if (!okb) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
     }
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem
+    if (nr > t_cap || nr < 0) {      // more targets than the caller's max_T said: the LDS arrays are sized by it
+        if (tid == 0) dm::raise_status(status, DM_ST_BAD_SIZES);
+        return;
+    }
 #ifdef DM_LAP_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long st_c1 = 0;
@@ -908,6 +916,10 @@ __global__ __launch_bounds__(64) void lap_generic_kernel(const DmSetArray sets, 
     if (!all_problems && transposed && Q <= fast_max_q) return;   // a register kernel's problem
     const int nr = transposed ? T : Q;
     const int nc = transposed ? Q : T;
+    if (T < 0 || nr > r_cap || nc > c_cap) {      // more targets than the caller's max_T said: the LDS arrays are sized by it
+        if (lane == 0) dm::raise_status(status, DM_ST_BAD_SIZES);
+        return;
+    }
 
     double *spc = reinterpret_cast<double *>(smem);      // [c_cap]
     double *v = spc + c_cap;                              // [c_cap]

@@ -68,8 +68,11 @@ class PendingNumBoxes:
             if self._side is not None:
                 # the collective and the clamp were enqueued on the side stream: the caller's stream waits for
                 # their event here (no host wait), and the tensor is marked as used on it
-                done, current = self._side
-                current.wait_event(done)
+                slot, generation, current = self._side
+                if slot.generation == generation:
+                    current.wait_event(slot.event)
+                # (else the slot has been handed out again since, which only happens after the host has seen this
+                # step's event complete: there is nothing left to wait for)
                 self._counts.record_stream(current)
                 self._done = self._counts
             else:
@@ -77,6 +80,41 @@ class PendingNumBoxes:
                     self._work.wait()
                 self._done = self._counts.clamp_(min=1.0)
         return self._done
+
+
+class _Slot:
+    """One step's pinned staging buffer and completion event.  A slot is handed out again only after the host
+    has seen its event complete -- the upload out of the buffer has run by then, however late a peer rank made
+    the collective behind it -- so a caller that never consumes `result()` (device-resident loops that do not
+    synchronise) can run any number of steps ahead without a buffer being overwritten under a pending copy."""
+
+    __slots__ = ("event", "staged", "generation", "recorded")
+
+    def __init__(self):
+        self.event = torch.cuda.Event()
+        self.staged = None
+        self.generation = 0
+        self.recorded = False
+
+
+_RING = 8
+_slot_rings = {}
+
+
+def _next_slot(device: torch.device, n: int) -> _Slot:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ring = _slot_rings.get(key)
+    if ring is None:
+        with torch.cuda.device(device):
+            ring = _slot_rings[key] = [[_Slot() for _ in range(_RING)], 0]
+    ring[1] = (ring[1] + 1) % _RING
+    slot = ring[0][ring[1]]
+    if slot.recorded and not slot.event.query():
+        slot.event.synchronize()          # the step that used this slot eight steps ago is still in flight
+    slot.generation += 1
+    if slot.staged is None or slot.staged.shape[0] != n:
+        slot.staged = torch.empty(n, dtype=torch.float32, pin_memory=True)
+    return slot
 
 
 def start_num_boxes_all_reduce(local_counts: Sequence[int], device, group=None, _always_reduce: bool = False) -> PendingNumBoxes:
@@ -103,51 +141,24 @@ def start_num_boxes_all_reduce(local_counts: Sequence[int], device, group=None, 
         work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group, async_op=True) if reduce else None
         return PendingNumBoxes(counts, work)
     side = _side_stream(device)
-    staged = _staging(device, len(scaled))
-    staged.numpy()[:] = scaled
+    slot = _next_slot(device, len(scaled))
+    slot.staged.numpy()[:] = scaled
     # (set_stream twice instead of the `torch.cuda.stream` context manager: a quarter of its cost)
     current = torch.cuda.current_stream(device)
     torch.cuda.set_stream(side)
     try:
-        counts = staged.to(device, non_blocking=True)        # pinned -> device, asynchronous
+        counts = slot.staged.to(device, non_blocking=True)        # pinned -> device, asynchronous
         if reduce:
             # The plain form: with the nccl backend it enqueues the collective on RCCL's stream and makes the
             # current stream -- the side stream here -- wait for it; the host does not block.  (async_op=True
             # followed by Work.wait() does the same for 35 us of host time instead of 8.)
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
         counts.clamp_(min=1.0)
-        done = _done_event(device)
-        done.record(side)
+        slot.event.record(side)
+        slot.recorded = True
     finally:
         torch.cuda.set_stream(current)
-    return PendingNumBoxes(counts, None, (done, current))
-
-
-_done_events = {}
-
-
-def _done_event(device: torch.device) -> "torch.cuda.Event":
-    """An event from a ring of eight per device (a fresh torch.cuda.Event per step costs more than recording one)."""
-    key = device.index
-    ring = _done_events.get(key)
-    if ring is None:
-        ring = _done_events[key] = [[torch.cuda.Event() for _ in range(8)], 0]
-    ring[1] = (ring[1] + 1) & 7
-    return ring[0][ring[1]]
-
-
-_staging_rings = {}
-
-
-def _staging(device: torch.device, n: int) -> torch.Tensor:
-    """A pinned float32 [n] host tensor from a small ring per device (eight steps may be in flight before a
-    buffer is written again; the copy out of it is enqueued before this function is called the next time)."""
-    key = (device.index, n)
-    ring = _staging_rings.get(key)
-    if ring is None:
-        ring = _staging_rings[key] = [[torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(8)], 0]
-    ring[1] = (ring[1] + 1) & 7
-    return ring[0][ring[1]]
+    return PendingNumBoxes(counts, None, (slot, slot.generation, current))
 
 
 def all_reduce_num_boxes(local_counts: Sequence[int], device, group=None) -> torch.Tensor:

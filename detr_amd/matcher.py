@@ -39,6 +39,22 @@ try:        # bulk creation of the per-image index views (csrc/index_views.cpp, 
     from . import _index_views
 except ImportError:      # not built: the views are made one by one in Python, same result
     _index_views = None
+if _index_views is not None and getattr(_index_views, "built_for_torch", None) != torch.__version__:
+    # the helper re-points live tensor objects through torch internals that are no stable interface: it is only
+    # used under the torch version it was compiled against (build_ext.py rebuilds it); the Python paths give the
+    # same results
+    import warnings
+
+    warnings.warn("detr_amd._index_views was built for torch %s, this is torch %s: not used (run build_ext.py)"
+                  % (getattr(_index_views, "built_for_torch", "?"), torch.__version__))
+    _index_views = None
+
+
+def _helper():
+    """The host helper module -- None while torch.compile traces the caller: Dynamo cannot look into a C
+    function and would break the graph (with a warning) at each of its calls, so tracing takes the tensor-only
+    Python paths, which give the same results."""
+    return None if torch.compiler.is_compiling() else _index_views
 
 
 class PackedTargets:
@@ -53,9 +69,10 @@ class PackedTargets:
         somebody needs them -- a step that runs as one fused kernel reads the targets where they are."""
         self.device = device
         self._source = self._scanned = None
-        if _index_views is not None and device.type == "cuda":
+        helper = _helper()
+        if helper is not None and device.type == "cuda":
             index = device.index if device.index is not None else torch.cuda.current_device()
-            scan = _index_views.scan_targets(targets, index)
+            scan = helper.scan_targets(targets, index)
             if scan is not None:          # the usual case: int64 labels, float32 [T, 4] boxes, contiguous, on `device`
                 self._pack_scanned(scan, device, index, defer)
                 return
@@ -165,7 +182,8 @@ class PackedTargets:
         """True when `targets` are the very tensors this object was packed from, unchanged since."""
         scanned = getattr(self, "_scanned", None)
         if scanned is not None:
-            return _index_views.same_targets(targets, scanned[0], scanned[1])
+            helper = _helper()
+            return helper is not None and helper.same_targets(targets, scanned[0], scanned[1])
         src = getattr(self, "_source", None)
         if src is None or len(targets) != self.batch:
             return False
@@ -343,6 +361,9 @@ class FlatMatches:
 
 
 def _raise_for_status(bits: int):
+    if bits & _lib.ST_BAD_SIZES:
+        # not one of the reference's errors: host-side sizes that contradict the device-side target offsets
+        raise RuntimeError("max_targets is smaller than an image's number of targets (device-side offsets)")
     # same precedence as the reference: the class-cost gather (IndexError) runs before the
     # box asserts (AssertionError), which run before scipy (ValueError)
     if bits & _lib.ST_LABEL_RANGE:
@@ -560,7 +581,8 @@ class HungarianMatcher(torch.nn.Module):
             cost = ops.cost(*common) if want_cost else None
             self.last_status = out[2 * S * M:2 * S * M + 1]
             return out, queries, cost, ops.set_array(None, queries, M)[2]
-        scan = _index_views.scan_outputs(outputs_list, batch, M) if _index_views is not None else None
+        helper = _helper()
+        scan = helper.scan_outputs(outputs_list, batch, M) if helper is not None else None
         if scan is not None:      # the usual case: float32, contiguous, one device, one class count
             index, C, queries, sets, cost_off = scan
             device = outputs_list[0]["pred_logits"].device
@@ -721,13 +743,19 @@ class HungarianMatcher(torch.nn.Module):
                 host.copy_(out[:n], non_blocking=True)
                 done = self._done_event(device)
                 done.record(torch.cuda.current_stream(device))     # the stream the kernels and the copy went to
-            if while_waiting is not None:
-                while_waiting()
-            # the per-image views depend on shapes only: build them while the GPU is working
-            if own:
-                result, status_at = self._split(host[1:], S, M, sizes, queries, packed.offsets_list), 0
-            else:
-                result, status_at = self._split(host, S, M, sizes, queries, packed.offsets_list), n - 1
+            try:
+                if while_waiting is not None:
+                    while_waiting()
+                # the per-image views depend on shapes only: build them while the GPU is working
+                if own:
+                    result, status_at = self._split(host[1:], S, M, sizes, queries, packed.offsets_list), 0
+                else:
+                    result, status_at = self._split(host, S, M, sizes, queries, packed.offsets_list), n - 1
+            except BaseException:
+                # the kernels (or the copy) are still writing into `host`: it must not go back to the pinned
+                # allocator, which knows nothing of that use, before they have finished
+                done.synchronize()
+                raise
             # by now the copy has normally landed: one event query is several times cheaper than a
             # stream synchronisation, which is only the fallback
             if not done.query():
@@ -748,8 +776,9 @@ class HungarianMatcher(torch.nn.Module):
         if M == 0:
             empty = flat[:0]
             return [[(empty, empty) for _ in sizes] for _ in range(S)]
-        if _index_views is not None and flat.dtype == torch.int64:
-            return _index_views.index_pairs(flat, M, sizes, queries, offsets)
+        helper = _helper()
+        if helper is not None and flat.dtype == torch.int64:
+            return helper.index_pairs(flat, M, sizes, queries, offsets)
         src_all, tgt_all = flat[:S * M], flat[S * M:2 * S * M]
         B = len(sizes)
         if min(queries) >= max(sizes):

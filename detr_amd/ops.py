@@ -15,6 +15,13 @@ Layouts (the C ABI's):
                                               stride_s = Q_s rounded up to 32
   lap   ->   int64 [2 * S * M + 1]             as match, from a cost buffer in that layout
 ``HungarianMatcher`` builds the reference's per-image tuples from these buffers.
+
+Precondition on the two host integers that describe the device-side ``tgt_meta``: ``num_targets`` is its
+last offset (the total number of targets, M) and ``max_targets`` is at least the largest difference of
+consecutive offsets.  The kernels size their LDS arrays by ``max_targets``: an image with more targets than
+that is skipped and reported through the status word (bit 16, ``RuntimeError`` from the matcher) instead of
+being solved out of bounds; ``num_targets`` smaller than the real total is NOT detected (the output regions
+are laid out with it) -- ``HungarianMatcher`` always passes consistent values.
 """
 import ctypes
 from typing import List, Sequence

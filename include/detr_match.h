@@ -57,6 +57,8 @@ extern "C" {
 #define DM_ST_DEGENERATE_BOX 2  /* AssertionError: x1<x0, y1<y0 or NaN (box_ops.py:59-60) */
 #define DM_ST_INVALID_COST 4    /* ValueError: NaN or -inf cost entry  (scipy, matcher.py:94) */
 #define DM_ST_INFEASIBLE 8      /* ValueError: cost matrix is infeasible (scipy) */
+#define DM_ST_BAD_SIZES 16      /* no counterpart: an image has more targets (tgt_off) than the call's max_T says;
+                                   that problem was skipped (the kernels size their LDS arrays by max_T) */
 
 /* One output set: the `output` dict of one matcher call (matcher.py:43-45). */
 typedef struct DmSet {

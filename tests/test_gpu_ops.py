@@ -107,7 +107,43 @@ def test_traced_by_torch_compile():
     def whole(outputs, tg):
         return matcher(outputs, tg)
 
-    got = torch.compile(whole, backend="aot_eager", fullgraph=False)(sets[0], targets)
+    import warnings
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = torch.compile(whole, backend="aot_eager", fullgraph=False)(sets[0], targets)
     want = matcher(sets[0], targets)
     for (a0, a1), (b0, b1) in zip(got, want):
         assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    # the host helper's C functions are not called while tracing: nothing for Dynamo to complain about
+    complaints = [str(w.message) for w in caught
+                  if "ynamo" in str(w.message) or "_index_views" in str(w.message) or "torch._dynamo" in (w.filename or "")]
+    assert not complaints, complaints
+
+
+def test_max_targets_smaller_than_the_offsets_say():
+    """The operators trust two host integers about the device-side offsets; max_targets too small must end in
+    the status word (bit 16), not in out-of-bounds LDS accesses -- in every assignment kernel."""
+    import detr_amd
+    from detr_amd import _lib
+
+    wl, sets, targets, matcher, packed = _workload("cfg2", 8)
+    S, M = len(sets), packed.total
+    args = list(_op_args(matcher, sets, packed))
+    assert packed.max_t >= 8
+    args[6] = packed.max_t // 2
+    cost = torch.ops.detr_amd.cost(*_op_args(matcher, sets, packed))
+    queries = [int(s["pred_logits"].shape[1]) for s in sets]
+    for mode in (0, 1, 2, 3):
+        _lib.set_knob("lap_kernel", mode)
+        try:
+            out = torch.ops.detr_amd.match(*args)
+            assert int(out[2 * S * M]) & _lib.ST_BAD_SIZES, mode
+            out = torch.ops.detr_amd.lap(cost, queries, packed.meta, M, packed.max_t // 2)
+            assert int(out[2 * S * M]) & _lib.ST_BAD_SIZES, mode
+            ok = torch.ops.detr_amd.lap(cost, queries, packed.meta, M, packed.max_t)
+            assert int(ok[2 * S * M]) == 0
+        finally:
+            _lib.set_knob("lap_kernel", 0)
+    with pytest.raises(RuntimeError, match="max_targets"):
+        detr_amd.matcher._raise_for_status(_lib.ST_BAD_SIZES)

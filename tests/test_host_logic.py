@@ -2,6 +2,8 @@
 and the data-parallel helpers (world_size 2 over gloo)."""
 import os
 import socket
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -350,3 +352,107 @@ def test_index_pairs_recycles_containers_only_when_nobody_holds_them():
         assert len(other) == 2 and other[1][1][1].tolist() == [10, 11]
     finally:
         iv.clear_pool()
+
+
+def test_index_view_helper_is_pinned_to_its_torch_version():
+    """The helper reaches into tensor internals; it says which torch it was compiled against and the matcher
+    module only keeps it under that very version."""
+    import detr_amd.matcher as mm
+
+    assert mm._index_views is not None
+    assert mm._index_views.built_for_torch == torch.__version__
+
+
+def _interleaved_user(name, steps, seed, errors, barrier=None):
+    """One caller of the shared helper: its own buffers, holds its latest result while the next is made (as a
+    training loop does) and checks every value of it after every call -- another caller's calls in between
+    must never show in them."""
+    rng = np.random.default_rng(seed)
+    held = None
+    try:
+        for k in range(steps):
+            S, B = int(rng.integers(1, 5)), int(rng.integers(1, 9))
+            if k % 3:                       # mostly a steady shape, so that recycling really happens
+                S, B = 3, 6
+            sizes = rng.integers(0, 5, B).tolist()
+            queries = rng.choice([2, 3, 50], S).tolist()
+            M = sum(sizes)
+            off = np.concatenate([[0], np.cumsum(sizes)]).astype(int).tolist()
+            flat = torch.arange(2 * S * M + 1, dtype=torch.int64) + 1000 * (k + 1) + seed
+            got = HungarianMatcher._split(flat, S, M, sizes, queries, off)
+            if barrier is not None and k % 7 == 0:
+                time.sleep(0)               # let the other thread in
+            for result, base, s_, m_, sz, qs, of in ((got, flat, S, M, sizes, queries, off),) + ((held,) if held else ()):
+                for s in range(s_):
+                    for b in range(len(sz)):
+                        n = min(sz[b], qs[s])
+                        lo = s * m_ + of[b]
+                        want0 = base[lo:lo + n]
+                        want1 = base[s_ * m_ + lo:s_ * m_ + lo + n]
+                        a0, a1 = result[s][b]
+                        if not (torch.equal(a0, want0) and torch.equal(a1, want1)):
+                            errors.append((name, k, s, b))
+            held = (got, flat, S, M, sizes, queries, off)
+    except Exception as exc:      # noqa: BLE001  (reported to the main thread)
+        errors.append((name, repr(exc)))
+
+
+def test_index_view_helper_shared_by_alternating_callers():
+    """Two matchers (Co-DETR: the Hungarian matcher and the auxiliary heads' matcher in one step) use the
+    helper's process-global pools in turn, each holding its own previous result: no held tensor ever changes."""
+    from detr_amd.matcher import _index_views as iv
+
+    iv.clear_pool()
+    errors = []
+    users = [dict(rng=np.random.default_rng(s), held=None) for s in (1, 2, 3)]
+    for k in range(200):
+        for u, user in enumerate(users):
+            S, B = (3, 6) if k % 4 else (int(user["rng"].integers(1, 5)), int(user["rng"].integers(1, 9)))
+            sizes = user["rng"].integers(0, 5, B).tolist()
+            queries = user["rng"].choice([2, 3, 50], S).tolist()
+            M = sum(sizes)
+            off = np.concatenate([[0], np.cumsum(sizes)]).astype(int).tolist()
+            flat = torch.arange(2 * S * M + 1, dtype=torch.int64) + 100000 * u + 100 * k
+            got = HungarianMatcher._split(flat, S, M, sizes, queries, off)
+            want = _python_split(flat, S, M, sizes, queries, off)
+            snapshot = [[(a.clone(), b.clone()) for a, b in per] for per in want]
+            for other in users:            # everything anybody still holds is as it was handed out
+                if other["held"] is None:
+                    continue
+                res, snap = other["held"]
+                for s in range(len(snap)):
+                    for (a0, a1), (w0, w1) in zip(res[s], snap[s]):
+                        if not (torch.equal(a0, w0) and torch.equal(a1, w1)):
+                            errors.append((k, u))
+            for s in range(S):
+                for (a0, a1), (w0, w1) in zip(got[s], snapshot[s]):
+                    if not (torch.equal(a0, w0) and torch.equal(a1, w1)):
+                        errors.append((k, u, "fresh"))
+            user["held"] = (got, snapshot)
+    iv.clear_pool()
+    assert not errors, errors[:5]
+
+
+def test_index_view_helper_from_two_threads():
+    """Two Python threads, each with its own buffers, interleave on the shared pools (every helper call runs
+    under the interpreter lock from start to end): each thread's results stay what they were."""
+    import threading
+
+    from detr_amd.matcher import _index_views as iv
+
+    iv.clear_pool()
+    errors = []
+    old = sys.getswitchinterval()
+    sys.setswitchinterval(1e-5)           # switch threads as often as the interpreter allows
+    try:
+        threads = [threading.Thread(target=_interleaved_user, args=("t%d" % i, 400, 10 + i, errors, True))
+                   for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+            assert not t.is_alive()
+    finally:
+        sys.setswitchinterval(old)
+        iv.clear_pool()
+    assert not errors, errors[:5]
