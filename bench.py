@@ -410,6 +410,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # rehearsal hook of the tests: this rank dies here, after its warm-up and before the first fence, where the
+    # other ranks will wait for it -- the parent of self-started ranks must end them and exit non-zero
+    if os.environ.get("DETR_AMD_BENCH_DIE_RANK") == str(rank):
+        os._exit(7)
 
     def timed_region(steps):
         """EXACTLY `steps` steps between two fences; returns seconds, MAX over ranks."""

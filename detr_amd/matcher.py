@@ -261,6 +261,19 @@ class PackedTargets:
             self._maps = (dev[0, :self.total], dev[1, :self.total])
         return self._maps
 
+    def _filled_slots(self, queries: int) -> torch.Tensor:
+        """Device int64 index of the packed slots a set of `queries` queries fills: the first min(Q, T_b) of every
+        image (an image with more targets than queries leaves the rest of its slots untouched).  Made on the host
+        from the sizes, uploaded from pinned memory without synchronising, kept per query count."""
+        cache = self.__dict__.setdefault("_filled", {})
+        dev = cache.get(queries)
+        if dev is None:
+            keep = np.flatnonzero(self.local_index < queries)
+            staged = torch.empty(keep.shape[0], dtype=torch.int64, pin_memory=True)
+            staged.numpy()[:] = keep
+            dev = cache[queries] = staged.to(self.device, non_blocking=True)
+        return dev
+
     @property
     def image_index(self) -> np.ndarray:
         """host int64 [M]: image of every packed target"""
@@ -838,9 +851,7 @@ class HungarianMatcher(torch.nn.Module):
                 flat_all = out[2 * S * M + 1:].view(S, M)             # written by the assignment kernel itself
             src, tgt, flat = both[0, s], both[1, s], flat_all[s]
             # images with more targets than queries leave holes: keep the first min(Q, T_b) slots
-            keep = np.concatenate([np.arange(o, o + min(q, t), dtype=np.int64)
-                                   for o, t in zip(packed.offsets_list[:-1], sizes)] + [np.zeros(0, np.int64)])
-            keep_dev = torch.from_numpy(keep).to(device)
+            keep_dev = packed._filled_slots(q)
             result.append(FlatMatches(batch_idx[keep_dev], src[keep_dev], tgt[keep_dev], flat[keep_dev], packed, q,
                                       (out, S), s))
         return result

@@ -72,6 +72,44 @@ def test_bench_strong_scaling_splits_the_batch():
     assert abs(rec["value"] - 64 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
 
 
+def test_rehearsal_eight_ranks_weak():
+    """What the driver's `python bench.py --gpus 8` runs, minus the hardware: eight self-started ranks (here all on
+    the one GPU, over gloo), every rank its own 64 images, fences and the MAX over ranks."""
+    rec = _bench("--gpus", "8", "--backend", "gloo", "--share-gpu")
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and rec["config"]["parallelism"] == "dp8"
+    assert "B=64 images per GPU (512 in total)" in rec["config"]["workload"]
+    assert abs(rec["value"] - 8 * 64 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
+
+
+def test_rehearsal_cfg5_share_of_a_rank():
+    """cfg5 as BASELINE states it, 128 images per GPU (the most the in-place target table holds), four ranks."""
+    rec = _bench("--gpus", "4", "--backend", "gloo", "--share-gpu", "--workload", "cfg5", "--batch", "128")
+    assert rec["n_gpus"] == 4 and "B=128 images per GPU (512 in total)" in rec["config"]["workload"]
+    assert rec["step_kernels"]["one_kernel_per_step"] is True
+
+
+def test_rehearsal_cfg4_strong_over_eight_ranks():
+    """cfg4's 256 images dealt to eight ranks by target count (32 each): the split BASELINE's config 4 describes."""
+    rec = _bench("--gpus", "8", "--backend", "gloo", "--share-gpu", "--workload", "cfg4", "--scaling", "strong")
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong"
+    assert "B=32 images per GPU (256 in total)" in rec["config"]["workload"]
+    assert abs(rec["value"] - 256 * 5 / (rec["ms_per_step"] * 5e-3)) < 1e-6 * rec["value"]
+
+
+def test_a_rank_that_dies_ends_the_run():
+    """A rank that dies before the first fence: the parent ends the ranks that wait for it and exits non-zero,
+    without a JSON line, well inside its timeout."""
+    import time
+
+    t0 = time.time()
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--share-gpu",
+                          "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=200,
+                         env=dict(os.environ, DETR_AMD_BENCH_DIE_RANK="2"))
+    assert run.returncode != 0 and "rank 2 exited with status 7" in run.stderr
+    assert not [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 120
+
+
 def test_bench_two_ranks_over_rccl():
     """One GPU per rank over RCCL (backend nccl): runs wherever the box has two GPUs."""
     import torch
