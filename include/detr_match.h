@@ -89,8 +89,9 @@ int dm_device_count(void);
 
 /*
  * Packs the per-image targets of a batch: replaces the two torch.cat calls of matcher.py:65-66 and
- * produces tgt_off / order as well, in one launch per 96 images and without any upload (pointers,
- * offsets and order travel as kernel arguments).
+ * produces tgt_off / order as well, in one launch: up to 96 images without any upload (pointers, offsets and
+ * order travel as kernel arguments), larger batches through a table in pinned host memory that the library keeps
+ * per host thread (the kernel reads it across the bus).
  *   pointers  host uint64[2 * B]: per image the device address of its int64 labels [T_b] and of its float32
  *             cxcywh boxes [T_b][4] (16-byte aligned), both contiguous
  *   meta      host int32[2 * B + 1]: tgt_off (B + 1 exclusive prefix sums of T_b), then the processing order (B)

@@ -144,6 +144,18 @@ def test_pack_kernel_equals_the_torch_packing():
         assert torch.equal(fast.meta, slow.meta)
         assert fast.same_targets(targets) and slow.same_targets(targets)
         assert not fast.same_targets(targets[:-1] + [dict(labels=targets[-1]["labels"].clone(), boxes=targets[-1]["boxes"])])
+    # batches beyond 96 images hand their table over in a ring of pinned slots: more packs in a row than the ring has
+    # slots, the batch growing in between (the ring is then re-made)
+    for k, batch in enumerate([130, 130, 300, 97, 300, 1024, 130, 1024, 200, 130, 130, 256]):
+        _, _, targets = synth.make_workload("cfg5", device="cuda", batch=batch, rank=k)
+        fast = detr_amd.PackedTargets(targets, device)
+        assert fast._scanned is not None
+        sizes = [len(t["labels"]) for t in targets]
+        assert torch.equal(fast.labels[:fast.total], torch.cat([t["labels"] for t in targets]))
+        assert torch.equal(fast.boxes[:fast.total], torch.cat([t["boxes"] for t in targets]))
+        meta = fast.meta.tolist()
+        assert meta[:batch + 1] == [sum(sizes[:b]) for b in range(batch + 1)]
+        assert meta[batch + 1:] == sorted(range(batch), key=lambda b: -sizes[b])
     # all images empty; int32 labels and float64 boxes take the general path (and its exceptions)
     empty = [{"labels": torch.zeros(0, dtype=torch.int64, device="cuda"), "boxes": torch.zeros(0, 4, device="cuda")}] * 3
     p = detr_amd.PackedTargets(empty, device)
