@@ -454,17 +454,11 @@ def main():
     # host side of a step takes 95 -> 88 us over steps 5..24 and 85 us from step ~40 on, while the kernel takes the
     # same 54 us from step 2 on.  (A gc.collect() right in front of a 20-step region costs it ~10 us per step of cold
     # caches: the paused region runs after the headline for that reason.)  The JSON line carries this as "order".
-    cost_ms_avg, lap_ms_avg = kernel_times(max(args.steps, 20))
-    elapsed = timed_region(args.steps)
-    gc.collect()
-    gc.disable()
-    try:
-        elapsed_paused = timed_region(args.steps)
-    finally:
-        gc.enable()
-
+    roofline = stress = None
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
+        # the two cost-kernel measurements (passes of their own, nothing of them inside the timed region) run FIRST:
+        # they are a few milliseconds of sustained GPU work, after which the headline region sees the clocks a
+        # training run sees, not those of a process that has just started
         # one kernel per step: the library computes the cost blocks inside the assignment kernel (C <= 4, every
         # T < Q, few enough problems for one workgroup each); asked of the library itself
         from detr_amd._lib import DmSet
@@ -485,6 +479,19 @@ def main():
         roofline = stress_roofline(device, launches=max(args.steps, 50), copy_reference=False,
                                    given=(wl, sets, targets))
         roofline["part_of_headline_step"] = not fused
+        if world == 1 and not args.no_stress:
+            stress = stress_roofline(device)
+    cost_ms_avg, lap_ms_avg = kernel_times(max(args.steps, 50))
+    elapsed = timed_region(args.steps)
+    gc.collect()
+    gc.disable()
+    try:
+        elapsed_paused = timed_region(args.steps)
+    finally:
+        gc.enable()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
         record = {
             "metric": "matched images/sec (Q=600, ~16 GT/img, 6 aux layers); cost-kernel HBM GB/s",
             "value": total_images * args.steps / elapsed,
@@ -502,7 +509,8 @@ def main():
                                    f"{wl.cls_loss} class cost, T~{wl.t_law} (sum T={sum(sizes)}, max T={max(sizes)}), "
                                    f"{len(wl.set_queries) * B} assignment problems per step per GPU",
                        "parallelism": f"dp{world}", "python_gc": "on",
-                       "order": f"{args.warmup} warm-up steps, kernel-event pass ({max(args.steps, 20)} steps), "
+                       "order": f"{args.warmup} warm-up steps, the cost-kernel passes (roofline, roofline_stress), "
+                                f"kernel-event pass ({max(args.steps, 50)} steps), "
                                 f"the headline region ({args.steps} steps), the collector-paused region ({args.steps} steps)"},
             "python_gc_paused": {"value": total_images * args.steps / elapsed_paused, "unit": "images/s",
                                  "ms_per_step": 1e3 * elapsed_paused / args.steps},
@@ -530,8 +538,8 @@ def main():
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
             record["per_layer_calls"] = per_layer_calls(matcher, sets, fresh, device, args.steps)
             record["per_layer_calls_prefetched"] = per_layer_calls(matcher, sets, fresh, device, args.steps, prefetch=True)
-        if world == 1 and not args.no_stress:
-            record["roofline_stress"] = stress_roofline(device)
+        if stress is not None:
+            record["roofline_stress"] = stress
         if world == 1 and not args.no_cpu_baseline:
             record["cpu_baseline"] = cpu_baseline(wl, sets, targets)
         print(json.dumps(record), flush=True)

@@ -664,6 +664,33 @@ class HungarianMatcher(torch.nn.Module):
         return out, queries, cost, strides
 
     @staticmethod
+    def _float32_inputs(outputs_list, targets):
+        """The reference computes in whatever dtype it is handed (matcher.py:59-90): float64 predictions and targets
+        work there, float64 logits beside float32 boxes too; prediction boxes and target boxes of different dtypes
+        raise RuntimeError (torch.cdist), half precision raises NotImplementedError.  The kernels compute in float32:
+        float64 inputs are rounded to float32 first (the cost then differs from the reference's float64 cost by
+        float32 rounding, ~1e-7 relative; the assignment only where two optima are that close)."""
+        first = outputs_list[0]
+        if first["pred_logits"].dtype == torch.float32 and first["pred_boxes"].dtype == torch.float32:
+            return outputs_list, targets           # the usual case: nothing to look at
+        allowed = (torch.float32, torch.float64)
+        packed = isinstance(targets, PackedTargets)
+        box_dtypes = {o["pred_boxes"].dtype for o in outputs_list}
+        box_dtypes |= {torch.float32} if packed else {t["boxes"].dtype for t in targets}
+        every = box_dtypes | {o["pred_logits"].dtype for o in outputs_list}
+        if any(d in (torch.float16, torch.bfloat16) for d in every):
+            raise NotImplementedError("half-precision matching inputs are not supported (the reference's torch.cdist "
+                                      "has no kernel for them either): cast predictions and targets to float32")
+        if len(box_dtypes) != 1 or not every <= set(allowed):
+            raise RuntimeError("prediction boxes and target boxes must have one floating dtype (float32 or float64), "
+                               "got %s" % sorted(str(d) for d in every))
+        outputs_list = [dict(o, pred_logits=o["pred_logits"].float(), pred_boxes=o["pred_boxes"].float())
+                        for o in outputs_list]
+        if not packed:
+            targets = [dict(t, boxes=t["boxes"].float()) for t in targets]
+        return outputs_list, targets
+
+    @staticmethod
     def _by_class_count(outputs_list):
         """None when all output sets have the same number of logits per query (one pass handles them);
         otherwise the positions of the sets of each class count -- heads with different class counts, e.g. a
@@ -716,6 +743,7 @@ class HungarianMatcher(torch.nn.Module):
         S = len(outputs_list)
         if S == 0:
             return []
+        outputs_list, targets = self._float32_inputs(outputs_list, targets)
         device = outputs_list[0]["pred_logits"].device
         packed = self._packed_for(targets, device)
         M, sizes = packed.total, packed.sizes
@@ -819,6 +847,7 @@ class HungarianMatcher(torch.nn.Module):
         S = len(outputs_list)
         if S == 0:
             return []
+        outputs_list, targets = self._float32_inputs(outputs_list, targets)
         groups = self._by_class_count(outputs_list)
         if groups is not None:
             result, statuses = [None] * S, []

@@ -55,6 +55,48 @@ class GoldenCase:
         return outputs, targets
 
 
+DTYPE_DIR = os.path.join(GOLDEN_DIR, "dtype")
+
+
+class DtypeCase:
+    """A golden case of tests/golden/dtype (made by gen_golden_dtypes.py): inputs in their own dtypes, the
+    reference's float64 cost blocks and indices, or the type name of the exception it raised."""
+
+    def __init__(self, name):
+        import torch
+
+        z = np.load(os.path.join(DTYPE_DIR, name + ".npz"), allow_pickle=False)
+        meta = json.loads(str(z["meta"]))
+        self.name, self.cls_loss, self.weights = name, meta["cls_loss"], tuple(meta["weights"])
+        self.error = {"RuntimeError": RuntimeError, "NotImplementedError": NotImplementedError}.get(meta["error"])
+        dts = [getattr(torch, d.split(".")[1]) for d in meta["dtypes"]]
+        self.sizes = z["sizes"].tolist()
+        self.logits = torch.from_numpy(z["logits"]).to(dts[0])
+        self.pboxes = torch.from_numpy(z["pboxes"]).to(dts[1])
+        self.B, self.Q, self.C = self.logits.shape
+        off = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
+        self.targets = [{"labels": torch.from_numpy(z["labels"][off[b]:off[b + 1]].copy()),
+                         "boxes": torch.from_numpy(z["tboxes"][off[b]:off[b + 1]].reshape(-1, 4).copy()).to(dts[2])}
+                        for b in range(self.B)]
+        self.cost = self.indices = None
+        if self.error is None:
+            self.cost, self.indices, pos, ipos = [], [], 0, 0
+            for t in self.sizes:
+                self.cost.append(z["cost"][pos:pos + self.Q * t].reshape(self.Q, t))
+                pos += self.Q * t
+                n = min(self.Q, t)
+                self.indices.append((z["src"][ipos:ipos + n], z["tgt"][ipos:ipos + n]))
+                ipos += n
+
+    def matcher_kwargs(self):
+        return dict(cls_loss=self.cls_loss, cost_class=self.weights[0], cost_bbox=self.weights[1],
+                    cost_giou=self.weights[2])
+
+
+def dtype_case_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(DTYPE_DIR, "*.npz")))
+
+
 def case_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 

@@ -441,3 +441,32 @@ def test_device_and_host_index_tuples_alternate():
                 assert b0.device.type == ("cuda" if k % 2 else "cpu")
                 assert torch.equal(a0, b0.cpu()) and torch.equal(a1, b1.cpu())
         del got
+
+
+@pytest.mark.parametrize("name", golden_io.dtype_case_names())
+def test_inputs_that_are_not_float32(name):
+    """float64 inputs (the reference computes in the dtype it is handed, matcher.py:59-90): the kernels round them
+    to float32 and compute there.  Against the reference's own float64 cost blocks and indices: cost within the
+    float32 bar, indices identical or of equal total cost; the reference's exceptions for mixed box dtypes
+    (RuntimeError) and half precision (NotImplementedError)."""
+    g = golden_io.DtypeCase(name)
+    matcher = _matcher(**g.matcher_kwargs())
+    outputs = {"pred_logits": g.logits.cuda(), "pred_boxes": g.pboxes.cuda()}
+    targets = [{k: v.cuda() for k, v in t.items()} for t in g.targets]
+    if g.error is not None:
+        with pytest.raises(g.error):
+            matcher(outputs, targets)
+        with pytest.raises(g.error):
+            matcher.match_flat([outputs], targets)
+        return
+    got = matcher(outputs, targets)
+    blocks = matcher.cost_blocks({k: v.float() for k, v in outputs.items()},
+                                 [dict(t, boxes=t["boxes"].float()) for t in targets])
+    for b, ((src, tgt), (rs, rt)) in enumerate(zip(got, g.indices)):
+        assert src.dtype == torch.int64 and src.device.type == "cpu"
+        ref_cost = g.cost[b]
+        golden_io.assert_cost_close(blocks[b].cpu().numpy(), ref_cost, g.logits[b].numpy(), g.targets[b]["labels"].numpy(),
+                                    g.cls_loss, g.weights[0], 0.25, 2.0)
+        _assert_same_or_equal_cost(ref_cost, (src, tgt), (rs, rt))
+    flat = matcher.match_flat([outputs], targets)[0]
+    assert torch.equal(flat.src_idx.cpu(), torch.cat([s for s, _ in got]))

@@ -110,8 +110,12 @@ def test_dtype_and_shape_errors():
     g = golden_io.load("ce_c3_q50")
     outputs, targets = g.torch_inputs("cuda")
     matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
-    with pytest.raises(RuntimeError):
-        matcher({"pred_logits": outputs["pred_logits"].double(), "pred_boxes": outputs["pred_boxes"]}, targets)
+    with pytest.raises(RuntimeError):      # box dtypes that differ (the reference's torch.cdist raises)
+        matcher({"pred_logits": outputs["pred_logits"], "pred_boxes": outputs["pred_boxes"].double()}, targets)
+    # float64 logits beside float32 boxes are fine in the reference (the sum is promoted), and here
+    same = matcher({"pred_logits": outputs["pred_logits"].double(), "pred_boxes": outputs["pred_boxes"]}, targets)
+    for (a0, a1), (b0, b1) in zip(same, matcher(outputs, targets)):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
     with pytest.raises(ValueError):
         matcher(outputs, targets[:-1])
 

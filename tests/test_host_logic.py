@@ -456,3 +456,27 @@ def test_index_view_helper_from_two_threads():
         sys.setswitchinterval(old)
         iv.clear_pool()
     assert not errors, errors[:5]
+
+
+def test_input_dtypes_follow_the_reference():
+    """float64 predictions / targets are accepted (rounded to float32), as the reference accepts them; box dtypes
+    that differ raise RuntimeError and half precision NotImplementedError, as tests/golden/dtype records for the
+    reference (matcher.py:59-90 on such inputs)."""
+    conv = HungarianMatcher._float32_inputs
+    mk = lambda ld, bd: {"pred_logits": torch.zeros(2, 3, 2, dtype=ld), "pred_boxes": torch.zeros(2, 3, 4, dtype=bd)}
+    tg = lambda bd: [{"labels": torch.zeros(1, dtype=torch.int64), "boxes": torch.zeros(1, 4, dtype=bd)} for _ in range(2)]
+    outs, t32 = [mk(torch.float32, torch.float32)], tg(torch.float32)
+    same_o, same_t = conv(outs, t32)
+    assert same_o is outs and same_t is t32                                    # the usual case is not touched
+    o, t = conv([mk(torch.float64, torch.float64)], tg(torch.float64))
+    assert o[0]["pred_logits"].dtype == o[0]["pred_boxes"].dtype == t[0]["boxes"].dtype == torch.float32
+    assert t[0]["labels"].dtype == torch.int64
+    o, t = conv([mk(torch.float64, torch.float32)], t32)                       # float64 logits beside float32 boxes
+    assert o[0]["pred_logits"].dtype == torch.float32
+    with pytest.raises(RuntimeError):
+        conv([mk(torch.float64, torch.float64)], t32)
+    for half in (torch.float16, torch.bfloat16):
+        with pytest.raises(NotImplementedError):
+            conv([mk(half, half)], tg(half))
+    with pytest.raises(RuntimeError):
+        conv([mk(torch.float64, torch.float64), mk(torch.float32, torch.float32)], tg(torch.float64))
