@@ -15,7 +15,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # DETR_AMD_LIB: an instrumented build of the same sources (profiling tools only)
 LIB_PATH = os.environ.get("DETR_AMD_LIB") or os.path.join(_PKG, "libdetr_match.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_SETS_PER_LAUNCH = 16
 NOALLOC_MAX_COST_FLOATS = 8 << 20
 
@@ -27,7 +27,8 @@ ST_LABEL_RANGE, ST_DEGENERATE_BOX, ST_INVALID_COST, ST_INFEASIBLE, ST_BAD_SIZES 
 class DmSet(ctypes.Structure):
     _fields_ = [("logits", ctypes.c_void_p), ("boxes", ctypes.c_void_p),
                 ("cost_off", ctypes.c_int64), ("out_off", ctypes.c_int64),
-                ("Q", ctypes.c_int32), ("q_stride", ctypes.c_int32)]
+                ("Q", ctypes.c_int32), ("q_stride", ctypes.c_int32),
+                ("logits_stride", ctypes.c_int32), ("boxes_stride", ctypes.c_int32)]
 
 
 class DmIndexSet(ctypes.Structure):

@@ -112,7 +112,7 @@ extern "C" int dm_match_fused_f32(const DmSet *sets, int S, int B, int C, const 
     if (!sets || !tgt_off || !src_out || !tgt_out || (max_T > 0 && (!tgt_labels || !tgt_boxes || !workspace)))
         return DM_E_INVALID_ARG;
     for (int s = 0; s < S; ++s)
-        if (!sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
+        if (!sets[s].logits || !sets[s].boxes || !dm::strides_ok(sets[s], C)) return DM_E_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned char generic[4096];      // sets whose cost blocks some kernel reads from memory
     int rc = dm::lap_plan(sets, S, B, max_T, generic);
@@ -176,7 +176,7 @@ extern "C" int dm_match_targets_f32(const DmSet *sets, int S, int B, int C, cons
     bool direct = !g_no_fuse && !g_no_direct && B <= dm::DIRECT_MAX_IMAGES && max_T > 0 && dm::lap_can_fuse(C, max_T) && S <= 4096;
     if (direct) {
         for (int s = 0; s < S; ++s)
-            if (!sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
+            if (!sets[s].logits || !sets[s].boxes || !dm::strides_ok(sets[s], C)) return DM_E_INVALID_ARG;
         unsigned char needs_cost[4096];
         int rc = dm::lap_plan(sets, S, B, max_T, needs_cost);
         if (rc != DM_OK) return rc;

@@ -90,11 +90,13 @@ __global__ __launch_bounds__(512, 2) void cost_small_kernel(const DmSetArray set
     // reference validates every prediction of the batch
     float4 raw[QPT];
     float x[QPT][4];
+    const float4 *img_boxes = image_boxes(set, b);
+    const float *img_logits = image_logits(set, b, C);
 #pragma unroll
     for (int i = 0; i < QPT; ++i) {
-        const size_t row = (size_t)b * Q + min(q0 + i, Q - 1);
-        raw[i] = reinterpret_cast<const float4 *>(set.boxes)[row];
-        const float *lg = set.logits + row * (size_t)C;
+        const int row = min(q0 + i, Q - 1);
+        raw[i] = img_boxes[row];
+        const float *lg = img_logits + (size_t)row * C;
 #pragma unroll
         for (int c = 0; c < 4; ++c) x[i][c] = c < C ? lg[c] : 0.0f;
     }
@@ -263,9 +265,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     const int nq = min(64, Q - q0);
     const int t0 = tgt_off[b];
     const int T = tgt_off[b + 1] - t0;
-    const size_t row = (size_t)b * Q + (active ? q : Q - 1);
-
-    const float4 raw = reinterpret_cast<const float4 *>(set.boxes)[row];
+    const float4 raw = image_boxes(set, b)[active ? q : Q - 1];
     // the first chunk of targets (one per thread) is requested before the tile, so that its latency
     // runs under the tile's: loads complete in order, and the records are built while the tile streams
     const bool stager = tid < min(TCHUNK, T);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(64 * W) void cost_tile_kernel(const DmSetArray sets
     }
     if (T > 0) {
         // stream the tile: rows q0 .. q0+nq-1 are contiguous in memory and stay so in LDS
-        const float *src = set.logits + ((size_t)b * Q + q0) * (size_t)C;
+        const float *src = image_logits(set, b, C) + (size_t)q0 * (size_t)C;
         const int n = nq * C;
 #if DM_TILE_ABL == 2
         if (false) {
@@ -485,19 +485,20 @@ __global__ __launch_bounds__(256) void cost_wide_kernel(const DmSetArray sets, c
     const bool active = q < Q;
     const int t0 = tgt_off[b];
     const int T = tgt_off[b + 1] - t0;
-    const size_t row = (size_t)b * Q + (active ? q : Q - 1);
-    const PredBox p = make_pred(reinterpret_cast<const float4 *>(set.boxes)[row]);
+    const int row = active ? q : Q - 1;
+    const PredBox p = make_pred(image_boxes(set, b)[row]);
     if (active && wave == 0 && !pred_valid(p)) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
     if (T == 0) return;
 
-    const float *xr = set.logits + row * (size_t)C;
+    const float *img_logits = image_logits(set, b, C);
+    const float *xr = img_logits + (size_t)row * (size_t)C;
     constexpr float LOG2E = 1.44269504088896f;
     float ce_max = 0.0f, ce_scale = 1.0f;
     if (MODE == 0) {
         const int sub = lane & 15;
         for (int g = 0; g < 16 / W; ++g) {
             const int r = 4 * wave + 4 * W * g + (lane >> 4);
-            const float *xrow = set.logits + ((size_t)b * Q + min(q0 + r, Q - 1)) * (size_t)C;
+            const float *xrow = img_logits + (size_t)min(q0 + r, Q - 1) * (size_t)C;
             float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
             int c = sub;
             for (; c + 48 < C; c += 64) {
@@ -655,7 +656,8 @@ extern "C" int dm_cost_f32(const DmSet *sets, int S, int B, int C, const int64_t
         int n = 0;
         for (int s = s0; s <= S; ++s) {
             if (s < S && !done[s] && sets[s].Q == Q) {
-                if (Q < 1 || sets[s].q_stride < Q || !sets[s].logits || !sets[s].boxes) return DM_E_INVALID_ARG;
+                if (Q < 1 || sets[s].q_stride < Q || !sets[s].logits || !sets[s].boxes || !dm::strides_ok(sets[s], C))
+                    return DM_E_INVALID_ARG;
                 arr.s[n++] = sets[s];
                 done[s] = true;
             }

@@ -185,15 +185,16 @@ __device__ __forceinline__ bool compute_cost_block(const DmSet &set, const Fused
     for (int i = tid; i < nr; i += nthreads) store_target(tg + i, tb[i], tl[i], C, status);
     __syncthreads();
     bool bad = false;
+    const float4 *img_boxes = image_boxes(set, b);
+    const float *img_logits = image_logits(set, b, C);
     // (Requesting the thread's first prediction ahead of the targets, to overlap the two memory latencies,
     // keeps the compiler from unrolling the pair loop below and measured 19 us slower at 384 problems.)
 #pragma unroll 1
     for (int k = 0; k < NCOL; ++k) {
         const int j = tid + nthreads * k;
         if (j >= nc) break;
-        const size_t row = (size_t)b * nc + j;
-        const float4 raw = reinterpret_cast<const float4 *>(set.boxes)[row];
-        const float *lg = set.logits + row * (size_t)C;
+        const float4 raw = img_boxes[j];
+        const float *lg = img_logits + (size_t)j * (size_t)C;
         float x[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) x[c] = c < C ? lg[c] : 0.0f;

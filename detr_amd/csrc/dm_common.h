@@ -17,6 +17,17 @@ namespace dm {
 
 constexpr int WAVE = 64;
 
+// First logit / first box of image b of a set (an image's rows are dense; images may lie further apart than
+// Q rows: stride 0 means they do not).
+__device__ __forceinline__ const float *image_logits(const DmSet &set, int b, int C)
+{
+    return set.logits + (size_t)b * (set.logits_stride ? (size_t)set.logits_stride : (size_t)set.Q * (size_t)C);
+}
+__device__ __forceinline__ const float4 *image_boxes(const DmSet &set, int b)
+{
+    return reinterpret_cast<const float4 *>(set.boxes + (size_t)b * (set.boxes_stride ? (size_t)set.boxes_stride : (size_t)set.Q * 4));
+}
+
 // DPP controls (GCN3/GFX9 encoding, all valid on gfx950)
 constexpr int DPP_QUAD_SWAP1 = 0xB1;   // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_SWAP2 = 0x4E;   // quad_perm:[2,3,0,1]
@@ -107,6 +118,14 @@ __device__ __forceinline__ int readlane_i32(int v, int lane)
 __device__ __forceinline__ void raise_status(int32_t *status, int bits)
 {
     atomicOr(status, bits);
+}
+
+// Image strides of a set: 0 (contiguous) or at least one image's rows; boxes stay 16-byte aligned.
+inline bool strides_ok(const DmSet &set, int C)
+{
+    if (set.logits_stride != 0 && (long long)set.logits_stride < (long long)set.Q * C) return false;
+    if (set.boxes_stride != 0 && (set.boxes_stride < set.Q * 4 || (set.boxes_stride & 3) != 0)) return false;
+    return (reinterpret_cast<uintptr_t>(set.boxes) & 15) == 0;
 }
 
 struct FusedIn;

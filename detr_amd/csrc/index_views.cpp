@@ -359,13 +359,28 @@ struct SetRecord {
     const void *logits, *boxes;
     int64_t cost_off, out_off;
     int32_t Q, q_stride;
+    int32_t logits_stride, boxes_stride;      // floats from one image to the next; 0 = contiguous
 };
-static_assert(sizeof(SetRecord) == 40, "must match DmSet");
+static_assert(sizeof(SetRecord) == 48, "must match DmSet");
+
+// [B, Q, K] with dense rows inside every image; the images themselves may lie further apart (what
+// tensor.split(sizes, dim=1) of a contiguous [B, Q + Q', K] tensor yields).  *image_stride: 0 when contiguous.
+bool rows_dense(const at::Tensor &t, int32_t *image_stride)
+{
+    const int64_t B = t.size(0), Q = t.size(1), K = t.size(2);
+    if (t.is_contiguous()) { *image_stride = 0; return true; }
+    if (t.stride(2) != 1 || t.stride(1) != K) return false;
+    const int64_t st = t.stride(0);
+    if (B > 1 && (st < Q * K || st > INT32_MAX)) return false;
+    *image_stride = B > 1 ? (int32_t)st : 0;
+    return true;
+}
 
 // scan_outputs(outputs_list, batch, num_targets) -> None, or
 //   (device_index, C, queries: list[int], descriptors: bytes (S DmSet records), cost_floats: int)
-// None unless every set has float32 contiguous pred_logits [batch, Q, C] and pred_boxes [batch, Q, 4] (16-byte
-// aligned) on one CUDA device with one C.  Cost regions are laid out one after the other, row stride = Q
+// None unless every set has float32 pred_logits [batch, Q, C] and pred_boxes [batch, Q, 4] (16-byte aligned, also
+// from image to image) with dense rows per image -- contiguous, or the images a fixed distance apart -- on one CUDA
+// device with one C.  Cost regions are laid out one after the other, row stride = Q
 // rounded up to 32; index regions at s * num_targets.
 struct OutputScan {
     std::vector<SetRecord> recs;
@@ -389,15 +404,18 @@ bool scan_output_sets(PyObject *outputs, long long batch, long long M, bool allo
         if (!l || !x) { ok = false; break; }
         ok = l->dim() == 3 && x->dim() == 3 && l->scalar_type() == at::kFloat && x->scalar_type() == at::kFloat &&
              l->size(0) == batch && x->size(0) == batch && l->size(1) == x->size(1) && x->size(2) == 4 &&
-             l->size(1) >= 1 && l->size(1) <= INT32_MAX - 32 && l->size(2) >= 1 && l->is_contiguous() &&
-             x->is_contiguous() && (l->device().is_cuda() || allow_host) && x->device() == l->device() &&
+             l->size(1) >= 1 && l->size(1) <= INT32_MAX - 32 && l->size(2) >= 1 &&
+             (l->device().is_cuda() || allow_host) && x->device() == l->device() &&
              (reinterpret_cast<uintptr_t>(x->data_ptr()) & 15) == 0;
+        int32_t l_stride = 0, x_stride = 0;
+        ok = ok && rows_dense(*l, &l_stride) && rows_dense(*x, &x_stride) && (x_stride & 3) == 0;
         if (!ok) break;
         if (s == 0) { r.C = l->size(2); r.device_index = l->device().index(); }
         ok = l->size(2) == r.C && l->device().index() == r.device_index;
         if (!ok) break;
         const int64_t Q = l->size(1), stride = (Q + 31) / 32 * 32;
-        r.recs[(size_t)s] = SetRecord{l->data_ptr(), x->data_ptr(), r.cost_off, (int64_t)s * M, (int32_t)Q, (int32_t)stride};
+        r.recs[(size_t)s] = SetRecord{l->data_ptr(), x->data_ptr(), r.cost_off, (int64_t)s * M, (int32_t)Q, (int32_t)stride,
+                                      l_stride, x_stride};
         r.cost_off += M * stride;
         PyList_SET_ITEM(r.queries, s, PyLong_FromLongLong(Q));
     }

@@ -543,7 +543,7 @@ __global__ __launch_bounds__((WIDE || NCOL == 1) ? 1024 : 64 * ((FAST_MAX_NCOL +
         // an image without targets: its predictions are still validated (the reference asserts on the whole batch)
         bool okb = true;
         for (int j = tid; j < nc; j += BS)
-            okb = okb && dm::pred_valid(dm::make_pred(reinterpret_cast<const float4 *>(set.boxes)[(size_t)b * nc + j]));
+            okb = okb && dm::pred_valid(dm::make_pred(dm::image_boxes(set, b)[j]));
         if (!okb) dm::raise_status(status, DM_ST_DEGENERATE_BOX);
     }
     if (nr == 0 || nr >= nc || nc > QCAP) return;   // not this kernel's problem

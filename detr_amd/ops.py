@@ -67,12 +67,31 @@ def check_predictions(pred_logits: Sequence[torch.Tensor], pred_boxes: Sequence[
             raise ValueError("all output sets must be on the same device")
         if logits.shape[1] == 0:
             raise ValueError("an output set has no queries")
-        logits, boxes = logits.contiguous(), boxes.contiguous()
-        if boxes.data_ptr() % 16:
-            boxes = boxes.clone()
+        # dense rows per image are enough (the tail of every image's queries that the denoising models hand over,
+        # pred_logits.split(sizes, dim=1)[1], is read in place); anything else is copied
+        if image_stride(logits) is None:
+            logits = logits.contiguous()
+        if image_stride(boxes) is None or boxes.data_ptr() % 16 or image_stride(boxes) % 4:
+            boxes = boxes.contiguous()
+            if boxes.data_ptr() % 16:
+                boxes = boxes.clone()
         keep.append((logits, boxes))
         queries.append(int(logits.shape[1]))
     return device, C, keep, queries
+
+
+def image_stride(t: torch.Tensor):
+    """Floats from one image to the next of a [B, Q, K] tensor whose rows are dense inside every image: 0 when the
+    tensor is contiguous, None when the kernels cannot read it in place."""
+    if t.is_contiguous():
+        return 0
+    B, Q, K = t.shape
+    if t.stride(2) != 1 or t.stride(1) != K:
+        return None
+    st = t.stride(0)
+    if B > 1 and (st < Q * K or st >= 2 ** 31):
+        return None
+    return int(st) if B > 1 else 0
 
 
 def set_array(keep, queries: Sequence[int], num_targets: int):
@@ -87,6 +106,7 @@ def set_array(keep, queries: Sequence[int], num_targets: int):
         d = sets[s]
         if keep is not None:
             d.logits, d.boxes = keep[s][0].data_ptr(), keep[s][1].data_ptr()
+            d.logits_stride, d.boxes_stride = image_stride(keep[s][0]), image_stride(keep[s][1])
         d.cost_off, d.out_off = cost_off, s * num_targets
         d.Q, d.q_stride = q, stride
         regions.append((cost_off, stride))

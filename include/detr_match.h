@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 1
+#define DM_ABI_VERSION 2
 #define DM_MAX_SETS_PER_LAUNCH 16
 
 /* return codes */
@@ -62,12 +62,19 @@ extern "C" {
 
 /* One output set: the `output` dict of one matcher call (matcher.py:43-45). */
 typedef struct DmSet {
-    const float *logits;  /* device, [B, Q, C] contiguous      (outputs["pred_logits"]) */
-    const float *boxes;   /* device, [B, Q, 4] contiguous cxcywh (outputs["pred_boxes"]) */
+    const float *logits;  /* device, [B, Q, C]: image b's rows start at logits + b * logits_stride, dense from there
+                             (outputs["pred_logits"]) */
+    const float *boxes;   /* device, [B, Q, 4] cxcywh, 16-byte aligned: image b's rows start at boxes + b * boxes_stride
+                             (outputs["pred_boxes"]) */
     int64_t cost_off;     /* element offset of this set's region in the cost buffer */
     int64_t out_off;      /* element offset of this set's region in src_out / tgt_out */
     int32_t Q;            /* queries per image */
     int32_t q_stride;     /* row stride of the cost region in floats, >= Q */
+    int32_t logits_stride; /* floats from one image's logits to the next; 0 = contiguous (Q * C).  The denoising models hand
+                              the matcher the tail of every image's queries -- pred_logits.split(sizes, dim=1)[1]
+                              (/root/reference/models/dino_detr/dino_func.py:164-182, dn_detr/dn_func.py:167-188) -- which is
+                              such a view: Q rows out of Q + Q_dn per image */
+    int32_t boxes_stride;  /* floats from one image's boxes to the next, a multiple of 4; 0 = contiguous (Q * 4) */
 } DmSet;
 
 /* Matcher hyper-parameters: HungarianMatcher.__init__ (matcher.py:21-36). */

@@ -32,7 +32,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_abi_version_and_strerror():
     import detr_amd
 
-    assert detr_amd.lib.dm_abi_version() == 1
+    assert detr_amd.lib.dm_abi_version() == 2
     assert detr_amd.lib.dm_strerror(0) == b"ok"
     assert b"invalid" in detr_amd.lib.dm_strerror(-1)
     assert detr_amd.lib.dm_device_count() >= 0
@@ -41,8 +41,9 @@ def test_abi_version_and_strerror():
 def test_struct_layouts_match_the_header():
     from detr_amd._lib import DmParams, DmSet
 
-    assert ctypes.sizeof(DmSet) == 40      # 2 pointers, 2 int64, 2 int32
+    assert ctypes.sizeof(DmSet) == 48      # 2 pointers, 2 int64, 4 int32
     assert DmSet.cost_off.offset == 16 and DmSet.Q.offset == 32 and DmSet.q_stride.offset == 36
+    assert DmSet.logits_stride.offset == 40 and DmSet.boxes_stride.offset == 44
     assert ctypes.sizeof(DmParams) == 24
 
 

@@ -185,3 +185,89 @@ def test_more_output_sets_than_one_launch_takes():
             assert torch.equal(a0, b0) and torch.equal(a1, b1)
         assert torch.equal(flats[s].src_idx.cpu(), torch.cat([i for i, _ in single]))
         assert torch.equal(maps[s], flats[s].target_classes(2))
+
+
+def _tail_views(sets, extra_rows):
+    """Every output set as the tail of a wider tensor, the way the denoising models hand the matched queries over:
+    pred_logits.split([n_dn, Q], dim=1)[1] (/root/reference/models/dino_detr/dino_func.py:164-182)."""
+    views = []
+    for k, o in enumerate(sets):
+        n_dn = extra_rows * (k + 1)
+        out = {}
+        for key, t in o.items():
+            B, Q, K = t.shape
+            wide = torch.full((B, n_dn + Q, K), float("nan"), dtype=t.dtype, device=t.device)
+            wide[:, n_dn:] = t
+            out[key] = wide.split([n_dn, Q], dim=1)[1]
+            assert not out[key].is_contiguous() or B == 1
+        views.append(out)
+    return views
+
+
+def _same_result(a, b):
+    for pa, pb in zip(a, b):
+        for (a0, a1), (b0, b1) in zip(pa, pb):
+            assert torch.equal(a0.cpu(), b0.cpu()) and torch.equal(a1.cpu(), b1.cpu())
+
+
+@pytest.mark.parametrize("name,batch,extra", [("cfg3_hw", 8, 10), ("cfg1", 5, 7), ("cfg2", 130, 4), ("cfg4", 6, 9),
+                                              ("cfg4_ce", 5, 3), ("wide_ce", 3, 5), ("cfg5", 300, 2)])
+def test_tails_of_wider_tensors_are_read_in_place(name, batch, extra):
+    """The matched queries of DN-DETR / DINO / Co-DETR are views with the images further apart than Q rows: the
+    kernels read them where they are (no copy), in every path -- one kernel, two kernels, the logit-tile and
+    the wide-class cost kernels, the wavefront-per-problem kernel -- with the results of the contiguous tensors."""
+    import detr_amd
+    import detr_amd.matcher as mm
+    from detr_amd import synth
+
+    wl, sets, targets = synth.make_workload(name, device="cuda", batch=batch)
+    views = _tail_views(sets, extra)
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    # the host helper takes them as they are and records the distance between images
+    packed = detr_amd.PackedTargets(targets, torch.device("cuda", torch.cuda.current_device()))
+    scan = mm._index_views.scan_outputs(views, packed.batch, packed.total)
+    assert scan is not None
+    from detr_amd._lib import DmSet
+    recs = (DmSet * len(views)).from_buffer_copy(scan[3])
+    for r, v in zip(recs, views):
+        assert r.logits == v["pred_logits"].data_ptr() and r.logits_stride == (v["pred_logits"].stride(0) if batch > 1 else 0)
+        assert r.boxes == v["pred_boxes"].data_ptr() and r.boxes_stride == (v["pred_boxes"].stride(0) if batch > 1 else 0)
+    base, base_cost = matcher.match_many(sets, targets, return_cost=True)
+    got, got_cost = matcher.match_many(views, targets, return_cost=True)
+    _same_result(base, got)
+    for a, b in zip(base_cost, got_cost):
+        assert torch.equal(a, b)
+    _same_result(base, matcher.match_many(views, targets))                          # CPU tuples, the usual call
+    _same_result(base, matcher.match_many(views, targets, device_indices=True))
+    _same_result([base[1]], [matcher(views[1], targets)])
+    for a, b in zip(matcher.match_flat(sets, targets), matcher.match_flat(views, targets)):
+        assert torch.equal(a.src_idx, b.src_idx) and torch.equal(a.tgt_flat, b.tgt_flat)
+    matcher.through_ops = True                                                      # the registered operators
+    _same_result(base, matcher.match_many(views, targets))
+    matcher.through_ops = False
+    detr_amd._lib.set_knob("no_fuse", 1)
+    try:
+        _same_result(base, matcher.match_many(views, targets))
+    finally:
+        detr_amd._lib.set_knob("no_fuse", 0)
+
+
+def test_strided_views_with_more_targets_than_queries_and_errors():
+    import detr_amd
+    from detr_amd import synth
+
+    g = golden_io.load("focal_t_gt_q")
+    outputs, targets = g.torch_inputs("cuda")
+    matcher = detr_amd.HungarianMatcher(**g.matcher_kwargs())
+    view = _tail_views([outputs], 3)[0]
+    _same_result([matcher(outputs, targets)], [matcher(view, targets)])
+    # a NaN in the rows the view does NOT cover is nobody's business; one inside it is
+    bad = {k: v.clone() for k, v in outputs.items()}
+    bad["pred_boxes"][1, 2, 0] = float("nan")
+    with pytest.raises(AssertionError):
+        matcher(_tail_views([bad], 3)[0], targets)
+    # rows that are not dense inside an image are copied (every other query of a wider tensor)
+    wide = {k: torch.repeat_interleave(v, 2, dim=1) for k, v in outputs.items()}
+    sparse = {k: v[:, ::2] for k, v in wide.items()}
+    assert not sparse["pred_boxes"].is_contiguous()
+    _same_result([matcher(outputs, targets)], [matcher(sparse, targets)])
