@@ -45,7 +45,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
 
 
 def measured_traffic(kernel, workload):
@@ -330,6 +330,9 @@ def main():
                          "dealt to the ranks by target count (detr_amd.dist.balanced_shards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the cfg4-size cost-kernel measurement")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the passes after the timed regions (flat path, per-layer calls): for profiler runs whose "
+                         "per-kernel averages should cover the headline step's launches only")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL); gloo for rehearsals")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (needs --backend gloo)")
@@ -534,7 +537,7 @@ def main():
                              "frac_of_hbm_peak": (step_bytes / (lap_ms_avg * 1e-3) / 1e9 / 8000.0) if fused and lap_ms_avg else None,
                              "bound": "latency (one workgroup per problem; the step takes as long as its heaviest problem)"},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
             record["per_layer_calls"] = per_layer_calls(matcher, sets, fresh, device, args.steps)
             record["per_layer_calls_prefetched"] = per_layer_calls(matcher, sets, fresh, device, args.steps, prefetch=True)

@@ -121,3 +121,28 @@ def test_attached_criterion_raises_what_the_loop_would():
     with pytest.raises(AssertionError):
         crit({"model": sets}, targets)
     assert crit.matcher._prefetched is None
+
+
+@pytest.mark.gpu
+def test_predictions_that_require_grad():
+    """In training the predictions are model outputs with a gradient history (and, for the denoising models,
+    non-contiguous views of them): matched as they are, nothing recorded on the autograd tape."""
+    import detr_amd
+    from detr_amd import synth
+    from detr_amd.criterion import attach
+
+    wl, sets, targets = synth.make_workload("cfg3", device="cuda", batch=6)
+    want = detr_amd.HungarianMatcher(**wl.matcher_kwargs).match_many(sets, targets)
+    want = [[(a.clone(), b.clone()) for a, b in per] for per in want]
+    live = []
+    for o in sets:
+        wide_l = torch.cat([torch.zeros_like(o["pred_logits"][:, :5]), o["pred_logits"]], dim=1).requires_grad_(True)
+        wide_b = torch.cat([torch.zeros_like(o["pred_boxes"][:, :5]), o["pred_boxes"]], dim=1).requires_grad_(True)
+        live.append({"pred_logits": (wide_l * 1.0).split([5, 300], dim=1)[1], "pred_boxes": (wide_b * 1.0).split([5, 300], dim=1)[1]})
+        assert live[-1]["pred_boxes"].requires_grad and not live[-1]["pred_boxes"].is_contiguous()
+    crit = LoopCriterion(types.SimpleNamespace(**wl.matcher_kwargs))
+    attach(crit)
+    assert crit({"model": live[:6], "first_stage": live[6:]}, targets) == 7
+    for got, ref in zip(crit.seen, want):
+        _same(got, ref)
+        assert not got[0][0].requires_grad

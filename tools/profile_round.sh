@@ -4,15 +4,15 @@
 #   (separate --pmc runs, kernel trace only), SQ counters of the step's kernel, and the per-workload
 #   kernel timings.  Everything lands under gpurun_out/<tag>_*; what is kept is copied to profiles/ by hand.
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o bench -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+    python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extras > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
+    python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- \
-    python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
+    python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/${TAG}_pmc_write.log 2>&1
 for w in cfg2 cfg4; do
     timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU \
         --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq_$w -- \
