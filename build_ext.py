@@ -62,8 +62,34 @@ def build_helper(force=False, verbose=False):
     return HELPER
 
 
+DEMO_SRC = os.path.join(ROOT, "tests", "c_abi", "abi_demo.c")
+DEMO = os.path.join(ROOT, "tests", "c_abi", "abi_demo")
+
+
+def build_demo(force=False, verbose=False):
+    """tests/c_abi/abi_demo: the matcher step from plain C (gcc; the HIP runtime's C API and libdetr_match.so, no torch),
+    run by tests/test_gpu_c_abi.py."""
+    newest = max(os.path.getmtime(DEMO_SRC), os.path.getmtime(LIB), os.path.getmtime(HEADERS[-1]))
+    if not force and os.path.exists(DEMO) and os.path.getmtime(DEMO) >= newest:
+        return DEMO
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-O1", "-Wall", "-std=c11", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
+           DEMO_SRC, "-o", DEMO, "-L", PKG, "-ldetr_match", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN/../../detr_amd", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DEMO
+
+
 def build_library(force=False, verbose=False):
     build_helper(force=force, verbose=verbose)
+    _build_kernels(force=force, verbose=verbose)
+    build_demo(force=force, verbose=verbose)
+    return LIB
+
+
+def _build_kernels(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
