@@ -481,21 +481,21 @@ class HungarianMatcher(torch.nn.Module):
         if not outputs_list:
             return
         results = self.match_many(outputs_list, targets)
+        packed = self._packed          # (what match_many has just made of `targets`: knows whether it is handed them again)
         table = {}
         for o, r in zip(outputs_list, results):
             l, x = o["pred_logits"], o["pred_boxes"]
-            table[id(o)] = (o, l, x, l._version, x._version, targets, r)
+            table[id(o)] = (o, l, x, l._version, x._version, targets, packed, r)
         state["_prefetched"] = table
 
     def clear_prefetched(self) -> None:
         self.__dict__["_prefetched"] = None
 
     def _prefetch_hit(self, hit, outputs, targets):
-        o, l, x, lv, xv, tg, result = hit
+        o, l, x, lv, xv, tg, packed, result = hit
         if o is not outputs or outputs["pred_logits"] is not l or outputs["pred_boxes"] is not x \
                 or l._version != lv or x._version != xv:
             return None
-        packed = self._packed
         if targets is not tg or packed is None or not packed.same_targets(targets):
             return None
         return result

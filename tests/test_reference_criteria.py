@@ -1,0 +1,170 @@
+"""detr_amd.criterion.attach on the REFERENCE's own Criterion classes (all six model families), in the build
+container only: the modules are loaded from /root/reference by path (the GPU box has no reference: skipped there).
+
+What is checked is the plumbing around the kernels, which needs no GPU: that `attach` finds the matcher and the
+`aux_flag` of each real criterion, that its forward pre-hook foresees exactly the output sets each criterion's loop
+hands to the matcher (`outputs['model']`, `outputs['first_stage']`, never the denoising groups), that the loop's calls
+are served from the one batched call, and that the loss comes out the same as with the reference's own matcher.
+The kernels are stood in for by the CPU oracle (tests may use it): `match_many` of the attached matcher is replaced by
+a function that returns the oracle's indices, so the test runs on CPU tensors.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference's source tree (build container only)")
+
+FAMILIES = ["detr", "conditional_detr", "dab_detr", "dn_detr", "dino_detr", "co_detr"]
+
+
+def _load(name, path, package_path=None):
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=package_path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="module")
+def reference():
+    """The reference's matcher and the six loss modules, loaded by path behind the stand-ins the container needs:
+    torchvision is absent (its box_area / box_iou are one-line definitions), and utils/misc.py imports PIL and
+    torchvision at module level although the criteria only take the logging helper AverageMeter from it."""
+    saved = dict(sys.modules)
+    tv, ops, bx = (types.ModuleType(n) for n in ("torchvision", "torchvision.ops", "torchvision.ops.boxes"))
+    bx.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+    def box_iou(a, b):
+        lt, rb = torch.max(a[:, None, :2], b[:, :2]), torch.min(a[:, None, 2:], b[:, 2:])
+        inter = (rb - lt).clamp(min=0).prod(-1)
+        return inter / (bx.box_area(a)[:, None] + bx.box_area(b) - inter)
+
+    ops.boxes, ops.box_iou, tv.ops = bx, box_iou, ops
+    sys.modules.update({"torchvision": tv, "torchvision.ops": ops, "torchvision.ops.boxes": bx})
+    for pkg in ("utils", "models"):
+        m = types.ModuleType(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    _load("utils.box_ops", os.path.join(REF, "utils/box_ops.py"))
+    misc = types.ModuleType("utils.misc")
+
+    class AverageMeter:
+        def update(self, val, n=1):
+            pass
+
+    misc.AverageMeter = AverageMeter
+    sys.modules["utils.misc"] = misc
+    matcher_mod = _load("models.matcher", os.path.join(REF, "models/matcher.py"))
+    losses = {}
+    for fam in FAMILIES:
+        pkg = types.ModuleType("models." + fam)
+        pkg.__path__ = [os.path.join(REF, "models", fam)]
+        sys.modules["models." + fam] = pkg
+        losses[fam] = _load(f"models.{fam}.loss", os.path.join(REF, "models", fam, "loss.py"))
+    yield matcher_mod, losses
+    for k in list(sys.modules):
+        if k not in saved:
+            del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def _boxes(n, gen):
+    return torch.cat([torch.rand(n, 2, generator=gen), torch.rand(n, 2, generator=gen) * 0.3 + 0.01], -1)
+
+
+def _set(B, Q, C, gen, n_dn=0):
+    """One output set; with n_dn the matched queries are the tail view the denoising models hand over."""
+    logits = torch.randn(B, n_dn + Q, C, generator=gen) * 2.0
+    boxes = _boxes(B * (n_dn + Q), gen).view(B, n_dn + Q, 4)
+    if n_dn:
+        (dl, ml), (db, mb) = logits.split([n_dn, Q], dim=1), boxes.split([n_dn, Q], dim=1)
+        return {"pred_logits": ml, "pred_boxes": mb}, {"pred_logits": dl, "pred_boxes": db}
+    return {"pred_logits": logits, "pred_boxes": boxes}, None
+
+
+def _inputs(fam, cls_loss, gen):
+    B, Q, L, n_cls, n_dn = 3, 40, 3, 2, 6
+    C = n_cls + 1 if cls_loss == "ce" else n_cls
+    sizes = [5, 0, 9]
+    targets = [{"labels": torch.randint(0, n_cls, (t,), generator=gen), "boxes": _boxes(t, gen)} for t in sizes]
+    denoising = fam in ("dn_detr", "dino_detr", "co_detr")
+    pairs = [_set(B, Q, C, gen, n_dn if denoising else 0) for _ in range(L)]
+    outputs = {"model": [p[0] for p in pairs]}
+    if denoising:
+        key = "noised" if fam == "dn_detr" else "cdn"
+        outputs[key] = [p[1] for p in pairs]
+        # the denoising groups bring their own targets and indices: query k of an image is matched to target k % T
+        dn_targets = [t for t in targets]
+        idx = [(torch.arange(min(n_dn, len(t["labels"]))), torch.arange(min(n_dn, len(t["labels"])))) for t in targets]
+        outputs[key + "_indices"], outputs[key + "_targets"] = idx, dn_targets
+    if fam in ("dino_detr", "co_detr"):
+        outputs["first_stage"] = [_set(B, 70, C, gen)[0]]
+    return outputs, targets, n_cls
+
+
+class _KnowsItsTargets:
+    def __init__(self, targets):
+        self.targets = targets
+
+    def same_targets(self, targets):
+        return targets is self.targets
+
+
+def _oracle_match_many(matcher, calls):
+    """Stands where the kernels are: the CPU oracle's indices for every set of the call, and the bookkeeping
+    `prefetch` relies on (what match_many has made of the targets)."""
+    from oracle import oracle
+
+    def match_many(outputs_list, targets, *args, **kwargs):
+        calls.append(len(outputs_list))
+        kw = dict(cls_loss=matcher.cls_loss, cost_class=matcher.cost_class, cost_bbox=matcher.cost_bbox,
+                  cost_giou=matcher.cost_giou, focal_alpha=matcher.focal_alpha, focal_gamma=matcher.focal_gamma)
+        result = []
+        for o in outputs_list:
+            ref = oracle.match(np.ascontiguousarray(o["pred_logits"].detach().numpy()),
+                               np.ascontiguousarray(o["pred_boxes"].detach().numpy()),
+                               [t["labels"].numpy() for t in targets], [t["boxes"].numpy() for t in targets], **kw)
+            result.append([(torch.from_numpy(np.asarray(i, dtype=np.int64)), torch.from_numpy(np.asarray(j, dtype=np.int64)))
+                           for i, j in ref])
+        matcher.__dict__["_packed"] = _KnowsItsTargets(targets)
+        return result
+
+    return match_many
+
+
+@pytest.mark.parametrize("aux_flag", [True, False])
+@pytest.mark.parametrize("cls_loss", ["ce", "focal"])
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_attach_on_the_references_own_criteria(reference, fam, cls_loss, aux_flag):
+    import detr_amd
+    from detr_amd.criterion import attach
+
+    matcher_mod, losses = reference
+    gen = torch.Generator().manual_seed(FAMILIES.index(fam) * 10 + (cls_loss == "ce") + 2 * aux_flag)
+    outputs, targets, n_cls = _inputs(fam, cls_loss, gen)
+    ref_matcher = matcher_mod.HungarianMatcher(cls_loss=cls_loss, cost_class=2.0, cost_bbox=5.0, cost_giou=2.0)
+    criterion = losses[fam].Criterion(matcher=ref_matcher, n_cls=n_cls, cls_loss=cls_loss, aux_flag=aux_flag)
+    want = criterion(outputs, targets)
+
+    matcher = attach(criterion)
+    assert isinstance(matcher, detr_amd.HungarianMatcher) and criterion.matcher is matcher
+    assert (matcher.cls_loss, matcher.cost_class, matcher.cost_bbox, matcher.cost_giou) == (cls_loss, 2.0, 5.0, 2.0)
+    calls = []
+    matcher.match_many = _oracle_match_many(matcher, calls)
+    got = criterion(outputs, targets)
+    # ONE batched call with exactly the sets the loop asks for; every call of the loop was served from it
+    n_model = len(outputs["model"]) if aux_flag else 1
+    n_first = len(outputs.get("first_stage", []))
+    assert calls == [n_model + n_first], (fam, calls)
+    assert matcher._prefetched is None
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    # and again with new targets objects (a new step)
+    fresh = [dict(t) for t in targets]
+    torch.testing.assert_close(criterion(outputs, fresh), want, rtol=1e-5, atol=1e-6)
+    assert calls == [n_model + n_first] * 2
