@@ -8,7 +8,8 @@ those calls is a kernel that takes as long as the heaviest image of the batch, p
 trip -- six or seven times per step.
 
 ``attach(criterion)`` swaps ``criterion.matcher`` for a :class:`detr_amd.HungarianMatcher` with the same
-hyper-parameters and registers a forward pre-hook on the criterion: when the criterion is called, the hook
+hyper-parameters (and Co-DETR's auxiliary assigners in ``criterion.aux_heads``,
+/root/reference/models/co_detr/loss.py:64,223-241, for their GPU counterparts in :mod:`detr_amd.aux_assign`) and registers a forward pre-hook on the criterion: when the criterion is called, the hook
 sees the whole ``outputs`` dict, matches all the sets the loop is going to ask for in ONE
 ``match_many`` call (``HungarianMatcher.prefetch``), and the loop's per-set calls find their result
 waiting.  The criterion's code stays as it is; a set the hook did not foresee is matched on the spot.
@@ -50,12 +51,32 @@ def sets_the_loop_will_match(outputs: dict, keys: Iterable[str] = MATCHED_KEYS, 
     return found
 
 
-def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS) -> HungarianMatcher:
+def aux_head_like(other):
+    """The detr_amd counterpart of one of the reference's auxiliary assigners
+    (/root/reference/models/co_detr/auxiliary_head.py:17-21, 63-67), told apart by the parameters they keep;
+    anything else is returned as it is."""
+    from . import aux_assign
+
+    if isinstance(other, (aux_assign.ATSS, aux_assign.FasterRCNN)):
+        return other
+    if hasattr(other, "pos_threshold") and hasattr(other, "neg_threshold"):
+        return aux_assign.FasterRCNN(other.pos_threshold, other.neg_threshold)
+    if hasattr(other, "k") and type(other).__name__.lower().startswith("atss"):
+        return aux_assign.ATSS(other.k)
+    return other
+
+
+def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_heads: bool = True) -> HungarianMatcher:
     """Make `criterion` (an instance of one of the reference's Criterion classes, or anything that keeps its
     matcher in ``.matcher`` and is called as ``criterion(outputs, targets)``) use the gfx950 matcher, all sets
-    of a step matched in one call.  Returns the matcher.  Calling it twice on one criterion is harmless."""
+    of a step matched in one call.  `aux_heads`: also swap the ATSS / Faster-RCNN assigners a Co-DETR criterion keeps
+    in its ``aux_heads`` dict.  Returns the matcher.  Calling it twice on one criterion is harmless."""
     matcher = matcher_like(criterion.matcher)
     criterion.matcher = matcher
+    heads = getattr(criterion, "aux_heads", None)
+    if aux_heads and isinstance(heads, dict):
+        for key in list(heads):
+            heads[key] = aux_head_like(heads[key])
     if getattr(criterion, "_detr_amd_hooks", None) is not None:
         return matcher
 

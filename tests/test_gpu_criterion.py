@@ -146,3 +146,27 @@ def test_predictions_that_require_grad():
     for got, ref in zip(crit.seen, want):
         _same(got, ref)
         assert not got[0][0].requires_grad
+
+
+@pytest.mark.gpu
+def test_attach_swaps_auxiliary_assigners_that_then_run_on_the_gpu():
+    """A Co-DETR-shaped criterion: its `aux_heads` dict holds objects with the reference's parameters; after attach
+    the same keys hold the GPU assigners, which give what the standalone ones give."""
+    import detr_amd
+    from detr_amd import aux_assign, synth
+    from detr_amd.criterion import attach
+
+    wl, sets, targets = synth.make_workload("cfg3", device="cuda", batch=5)
+    crit = LoopCriterion(types.SimpleNamespace(**wl.matcher_kwargs))
+
+    class ATSSLike:          # what the reference's ATSS object exposes
+        k = 9
+
+    crit.aux_heads = {"atss": ATSSLike(), "faster_rcnn": types.SimpleNamespace(pos_threshold=0.7, neg_threshold=0.3)}
+    attach(crit)
+    assert isinstance(crit.aux_heads["atss"], aux_assign.ATSS) and isinstance(crit.aux_heads["faster_rcnn"], aux_assign.FasterRCNN)
+    got = crit.aux_heads["atss"](sets[0], targets)
+    want = aux_assign.ATSS(9)(sets[0], targets)
+    assert len(got) == 5 and all(torch.equal(a0, b0) and torch.equal(a1, b1) for (a0, a1), (b0, b1) in zip(got, want))
+    pos, neg = crit.aux_heads["faster_rcnn"](sets[1], targets)
+    assert len(pos) == 5 and len(neg) == 5

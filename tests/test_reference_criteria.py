@@ -168,3 +168,26 @@ def test_attach_on_the_references_own_criteria(reference, fam, cls_loss, aux_fla
     fresh = [dict(t) for t in targets]
     torch.testing.assert_close(criterion(outputs, fresh), want, rtol=1e-5, atol=1e-6)
     assert calls == [n_model + n_first] * 2
+
+
+def test_attach_swaps_the_auxiliary_assigners_of_co_detr(reference):
+    """Co-DETR keeps its ATSS / Faster-RCNN assigners in a plain dict on the criterion (co_detr/loss.py:64): attach
+    replaces them by the GPU ones with the same parameters."""
+    from detr_amd import aux_assign
+    from detr_amd.criterion import attach
+
+    matcher_mod, losses = reference
+    aux_mod = sys.modules["models.co_detr.auxiliary_head"]
+    args = types.SimpleNamespace(aux_heads=["atss", "faster_rcnn"], atss_k=7)
+    heads = aux_mod.get_aux_heads(args)
+    heads["faster_rcnn"].pos_threshold = 0.6
+    criterion = losses["co_detr"].Criterion(matcher=matcher_mod.HungarianMatcher("focal", 2.0, 5.0, 2.0), n_cls=2,
+                                            cls_loss="focal", aux_heads=heads)
+    attach(criterion)
+    assert isinstance(criterion.aux_heads["atss"], aux_assign.ATSS) and criterion.aux_heads["atss"].k == 7
+    rcnn = criterion.aux_heads["faster_rcnn"]
+    assert isinstance(rcnn, aux_assign.FasterRCNN) and (rcnn.pos_threshold, rcnn.neg_threshold) == (0.6, 0.3)
+    keep = losses["co_detr"].Criterion(matcher=matcher_mod.HungarianMatcher("focal", 2.0, 5.0, 2.0), n_cls=2,
+                                       cls_loss="focal", aux_heads=aux_mod.get_aux_heads(args))
+    attach(keep, aux_heads=False)
+    assert type(keep.aux_heads["atss"]).__module__ == "models.co_detr.auxiliary_head"
