@@ -596,7 +596,7 @@ class HungarianMatcher(torch.nn.Module):
             return out, queries, cost, ops.set_array(None, queries, M)[2]
         helper = _helper()
         scan = helper.scan_outputs(outputs_list, batch, M) if helper is not None else None
-        if scan is not None:      # the usual case: float32, contiguous, one device, one class count
+        if scan is not None:      # the usual case: float32, rows dense within every image, one device, one class count
             index, C, queries, sets, cost_off = scan
             device = outputs_list[0]["pred_logits"].device
             keep = None
