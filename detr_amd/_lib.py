@@ -33,7 +33,7 @@ class DmSet(ctypes.Structure):
 
 class DmIndexSet(ctypes.Structure):
     _fields_ = [("pred_boxes", ctypes.c_void_p), ("grad_boxes", ctypes.c_void_p), ("target_cls", ctypes.c_void_p),
-                ("out_off", ctypes.c_int64), ("Q", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("out_off", ctypes.c_int64), ("Q", ctypes.c_int32), ("boxes_stride", ctypes.c_int32)]
 
 
 class DmParams(ctypes.Structure):

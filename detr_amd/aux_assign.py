@@ -15,7 +15,7 @@ from typing import Dict, List, Sequence, Tuple, Union
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import DmIndexSet, lib
 from .matcher import PackedTargets
 
@@ -44,11 +44,15 @@ def _prepare(outputs_list, targets):
             raise ValueError("pred_boxes must be [B, Q, 4] with B = len(targets)")
         if boxes.dtype != torch.float32:
             raise RuntimeError(f"pred_boxes must be float32, got {boxes.dtype}")
-        boxes = boxes.detach().contiguous()
-        if boxes.data_ptr() % 16:
-            boxes = boxes.clone()
+        boxes = boxes.detach()
+        stride = ops.image_stride(boxes)          # rows dense inside every image are read in place; else a copy
+        if stride is None or stride % 4 or boxes.data_ptr() % 16:
+            boxes = boxes.contiguous()
+            if boxes.data_ptr() % 16:
+                boxes = boxes.clone()
         keep.append(boxes)
         sets[i].pred_boxes, sets[i].Q = boxes.data_ptr(), int(boxes.shape[1])
+        sets[i].boxes_stride = ops.image_stride(boxes)
     return device, packed, sets, keep
 
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void atss_kernel(const DmIndexSetArray sets, co
     const int t = blockIdx.x, lane = threadIdx.x, Q = set.Q;
     const int b = image_of_slot(tgt_off, B, t);
     const float4 gb = reinterpret_cast<const float4 *>(tgt_boxes)[t];
-    const float4 *pred = reinterpret_cast<const float4 *>(set.pred_boxes) + (size_t)b * Q;
+    const float4 *pred = dm::image_pred_boxes(set, b);
 
     // k rounds of "smallest key above the last one", key = (distance bits, prediction index):
     // distances are >= 0, so their bit patterns order like the values
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void rcnn_pos_kernel(const DmIndexSetArray sets
     const int t = blockIdx.x, lane = threadIdx.x, Q = set.Q;
     const int b = image_of_slot(tgt_off, B, t);
     const Corners g = corners(reinterpret_cast<const float4 *>(tgt_boxes)[t]);
-    const float4 *pred = reinterpret_cast<const float4 *>(set.pred_boxes) + (size_t)b * Q;
+    const float4 *pred = dm::image_pred_boxes(set, b);
     const size_t slot = (size_t)blockIdx.y * M + t;
     float top = -1.0f;
     int top_q = 0x7fffffff;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64) void rcnn_neg_kernel(const DmIndexSetArray sets
     const int first = tgt_off[b], T = tgt_off[b + 1] - first;
     bool negative = q < Q;
     if (q < Q && T > 0) {
-        const Corners p = corners(reinterpret_cast<const float4 *>(set.pred_boxes)[(size_t)b * Q + q]);
+        const Corners p = corners(dm::image_pred_boxes(set, b)[q]);
         float top = -__builtin_huge_valf();
         for (int t = 0; t < T; ++t)
             top = fmaxf(top, iou_of(corners(reinterpret_cast<const float4 *>(tgt_boxes)[first + t]), p));
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void rcnn_dense_kernel(const DmIndexSetArray se
     int64_t value = n_cls;
     int pairs = 0;
     if (q < Q && T > 0) {
-        const Corners p = corners(reinterpret_cast<const float4 *>(set.pred_boxes)[(size_t)b * Q + q]);
+        const Corners p = corners(dm::image_pred_boxes(set, b)[q]);
         const int32_t *bst = best + (size_t)blockIdx.z * M + first;
         float top = -__builtin_huge_valf();
         int winner = -1;
@@ -218,7 +218,7 @@ int check_sets(const DmIndexSet *sets, int S, int B, int M)
     if (S < 0 || B < 0 || M < 0 || (S > 0 && !sets)) return DM_E_INVALID_ARG;
     if (B > 65535) return DM_E_UNSUPPORTED;
     for (int s = 0; s < S; ++s)
-        if (sets[s].Q < 1 || !sets[s].pred_boxes) return DM_E_INVALID_ARG;
+        if (sets[s].Q < 1 || !sets[s].pred_boxes || !dm::index_set_boxes_ok(sets[s])) return DM_E_INVALID_ARG;
     return DM_OK;
 }
 

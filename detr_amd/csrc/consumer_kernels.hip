@@ -99,6 +99,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void pair_loss_kernel(const DmIndexSe
     const DmIndexSet &set = sets.s[blockIdx.x];
     const int Q = set.Q;
     const float4 *pred = reinterpret_cast<const float4 *>(set.pred_boxes);
+    const size_t image_rows = set.boxes_stride ? (size_t)(set.boxes_stride >> 2) : (size_t)Q;      // float4 rows from image to image
     const float4 *gts = reinterpret_cast<const float4 *>(tgt_boxes);
     float l1 = 0.0f, gl = 0.0f;
     for (int k = threadIdx.x; k < M; k += LOSS_THREADS) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void pair_loss_kernel(const DmIndexSe
         if (k - first < n) {
             const int64_t q = src[set.out_off + k];
             const int64_t t = first + tgt[set.out_off + k];
-            const float4 pb = pred[(size_t)b * Q + q];
+            const float4 pb = pred[(size_t)b * image_rows + q];
             const float4 gb = gts[t];
             const float d0 = pb.x - gb.x, d1 = pb.y - gb.y, d2 = pb.z - gb.z, d3 = pb.w - gb.w;
             l1 += ((fabsf(d0) + fabsf(d1)) + fabsf(d2)) + fabsf(d3);
@@ -212,7 +213,7 @@ extern "C" int dm_pair_loss_f32(const DmIndexSet *sets, int S, int B, int M, con
         const int n = std::min(DM_MAX_SETS_PER_LAUNCH, S - s0);
         DmIndexSetArray arr;
         for (int i = 0; i < n; ++i) {
-            if (!sets[s0 + i].pred_boxes) return DM_E_INVALID_ARG;
+            if (!sets[s0 + i].pred_boxes || !dm::index_set_boxes_ok(sets[s0 + i])) return DM_E_INVALID_ARG;
             arr.s[i] = sets[s0 + i];
         }
         hipLaunchKernelGGL(pair_loss_kernel, dim3(n), dim3(LOSS_THREADS), 0, st, arr, B, M, tgt_boxes, tgt_off, src, tgt,

@@ -120,6 +120,18 @@ __device__ __forceinline__ void raise_status(int32_t *status, int bits)
     atomicOr(status, bits);
 }
 
+// Prediction boxes of image b for the consumers of the indices and the auxiliary assigners (DmIndexSet).
+__device__ __forceinline__ const float4 *image_pred_boxes(const DmIndexSet &set, int b)
+{
+    return reinterpret_cast<const float4 *>(set.pred_boxes) +
+           (size_t)b * (set.boxes_stride ? (size_t)(set.boxes_stride >> 2) : (size_t)set.Q);
+}
+inline bool index_set_boxes_ok(const DmIndexSet &set)
+{
+    if (set.boxes_stride != 0 && (set.boxes_stride < set.Q * 4 || (set.boxes_stride & 3) != 0)) return false;
+    return (reinterpret_cast<uintptr_t>(set.pred_boxes) & 15) == 0;
+}
+
 // Image strides of a set: 0 (contiguous) or at least one image's rows; boxes stay 16-byte aligned.
 inline bool strides_ok(const DmSet &set, int C)
 {

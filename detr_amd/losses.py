@@ -13,7 +13,7 @@ from typing import List, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from ._lib import DmIndexSet, lib
 from .matcher import FlatMatches
 
@@ -32,6 +32,7 @@ def _index_sets(flats, M, pred=None, grad=None, cls=None):
     sets = (DmIndexSet * len(flats))()
     for i, f in enumerate(flats):
         sets[i].pred_boxes = pred[i].data_ptr() if pred is not None else None
+        sets[i].boxes_stride = ops.image_stride(pred[i]) if pred is not None else 0
         sets[i].grad_boxes = grad[i].data_ptr() if grad is not None else None
         sets[i].target_cls = cls[i].data_ptr() if cls is not None else None
         sets[i].out_off, sets[i].Q = f.set_index * M, f.queries
@@ -50,8 +51,14 @@ class _PairLossSums(torch.autograd.Function):
         for f, p in zip(flats, pred_boxes):
             if p.dtype != torch.float32 or p.dim() != 3 or tuple(p.shape) != (B, f.queries, 4) or p.device != device:
                 raise ValueError("pred_boxes must be float32 [B, Q, 4] on the device of the indices")
-            p = p.detach().contiguous()
-            boxes.append(p if p.data_ptr() % 16 == 0 else p.clone())
+            p = p.detach()
+            # rows dense inside every image are read in place (the tail views of the denoising models); else a copy
+            stride = ops.image_stride(p)
+            if stride is None or stride % 4 or p.data_ptr() % 16:
+                p = p.contiguous()
+                if p.data_ptr() % 16:
+                    p = p.clone()
+            boxes.append(p)
         n = len(flats)
         sums = torch.empty(n, 2, dtype=torch.float32, device=device)
         pair_grad = torch.empty(n, max(M, 1), 8, dtype=torch.float32, device=device)

@@ -227,12 +227,13 @@ int dm_noalloc_scratch(float **ptr, uint64_t *floats);
  * (same layout, same out_off); everything stays on the device.
  */
 typedef struct DmIndexSet {
-    const float *pred_boxes; /* device [B, Q, 4] cxcywh (dm_pair_loss_f32) or NULL */
+    const float *pred_boxes; /* device [B, Q, 4] cxcywh, 16-byte aligned, image b's rows at pred_boxes + b * boxes_stride
+                                (dm_pair_loss_f32, the auxiliary assigners) or NULL */
     float *grad_boxes;       /* device [B, Q, 4], every element written (dm_pair_loss_backward_f32) or NULL */
     int64_t *target_cls;     /* device [B, Q], every element written (dm_target_classes_i64) or NULL */
     int64_t out_off;         /* element offset of the set's region in src / tgt */
     int32_t Q;               /* queries per image */
-    int32_t reserved;
+    int32_t boxes_stride;    /* floats from one image's prediction boxes to the next, a multiple of 4; 0 = contiguous (Q * 4) */
 } DmIndexSet;
 
 /*

@@ -134,3 +134,42 @@ def test_bitwise_reproducible_and_rejects_foreign_sets():
         losses.matched_box_losses(sets[:2], [flats[0], other[1]])
     with pytest.raises(ValueError):
         losses.matched_box_losses([{"pred_boxes": sets[0]["pred_boxes"].double()}], flats[:1])
+
+
+def test_tail_views_of_wider_tensors_losses_and_aux_assigners():
+    """The matched queries of the denoising models are views with the images further apart than Q rows
+    (pred_boxes.split([n_dn, Q], dim=1)[1]): the pair-loss kernel and the auxiliary assigners read them in place;
+    losses, gradients (w.r.t. the WIDE tensor, through the view) and assignments equal those of contiguous copies."""
+    import detr_amd
+    from detr_amd import aux_assign, losses, synth
+
+    wl, sets, targets = synth.make_workload("cfg3", device="cuda", batch=6)
+    sets = sets[:3]
+    n_dn = 7
+    wide, views = [], []
+    for o in sets:
+        wb = torch.cat([torch.rand_like(o["pred_boxes"][:, :n_dn]), o["pred_boxes"]], dim=1).requires_grad_(True)
+        wl_ = torch.cat([torch.zeros_like(o["pred_logits"][:, :n_dn]), o["pred_logits"]], dim=1)
+        wide.append(wb)
+        views.append({"pred_logits": wl_.split([n_dn, 300], dim=1)[1], "pred_boxes": wb.split([n_dn, 300], dim=1)[1]})
+        assert not views[-1]["pred_boxes"].is_contiguous()
+    dense = [{"pred_logits": o["pred_logits"], "pred_boxes": o["pred_boxes"].clone().requires_grad_(True)} for o in sets]
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    flats_v, flats_d = matcher.match_flat(views, targets), matcher.match_flat(dense, targets)
+    total_v = losses.matched_box_loss_total(views, flats_v, 5.0, 2.0)
+    total_d = losses.matched_box_loss_total(dense, flats_d, 5.0, 2.0)
+    assert torch.equal(total_v, total_d)
+    grads_v = torch.autograd.grad(total_v, wide)
+    grads_d = torch.autograd.grad(total_d, [o["pred_boxes"] for o in dense])
+    for gv, gd in zip(grads_v, grads_d):
+        assert torch.equal(gv[:, n_dn:], gd) and not gv[:, :n_dn].any()
+    def same(x, y):
+        if isinstance(x, torch.Tensor):
+            return torch.equal(x, y)
+        return len(x) == len(y) and all(same(p, q) for p, q in zip(x, y))
+
+    for head in (aux_assign.ATSS(9), aux_assign.FasterRCNN()):
+        assert same(head.assign_many(views, targets), head.assign_many(dense, targets))
+    maps_v, n_v = aux_assign.FasterRCNN().dense_class_targets(views, targets, 2)
+    maps_d, n_d = aux_assign.FasterRCNN().dense_class_targets(dense, targets, 2)
+    assert torch.equal(n_v, n_d) and all(torch.equal(x, y) for x, y in zip(maps_v, maps_d))
