@@ -66,11 +66,17 @@ def aux_head_like(other):
     return other
 
 
-def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_heads: bool = True) -> HungarianMatcher:
+def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_heads: bool = True,
+           device_indices: bool = False) -> HungarianMatcher:
     """Make `criterion` (an instance of one of the reference's Criterion classes, or anything that keeps its
     matcher in ``.matcher`` and is called as ``criterion(outputs, targets)``) use the gfx950 matcher, all sets
     of a step matched in one call.  `aux_heads`: also swap the ATSS / Faster-RCNN assigners a Co-DETR criterion keeps
-    in its ``aux_heads`` dict.  Returns the matcher.  Calling it twice on one criterion is harmless."""
+    in its ``aux_heads`` dict.  `device_indices`: the loop is handed device-resident index tensors instead of the
+    reference's CPU tensors -- its gathers then need no index upload (the reference's loss expressions on a
+    64-image, 6-set step: 12 ms instead of 24 ms) and the host never waits for the matcher; the reference's
+    exceptions for bad inputs are raised when the criterion returns (one synchronisation per step, where the
+    reference's criteria synchronise anyway to log ``total_loss.item()``).  Returns the matcher.  Calling it twice
+    on one criterion is harmless."""
     matcher = matcher_like(criterion.matcher)
     criterion.matcher = matcher
     heads = getattr(criterion, "aux_heads", None)
@@ -86,13 +92,17 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
         m = module.matcher
         if not isinstance(m, HungarianMatcher) or outputs is None or targets is None:
             return None
-        m.prefetch(sets_the_loop_will_match(outputs, keys, last_only=not getattr(module, "aux_flag", True)), targets)
+        m.prefetch(sets_the_loop_will_match(outputs, keys, last_only=not getattr(module, "aux_flag", True)), targets,
+                   device_indices=device_indices)
         return None
 
     def after(module, args, kwargs, result):
         m = module.matcher
         if isinstance(m, HungarianMatcher):
+            served = m._prefetched is not None
             m.clear_prefetched()
+            if device_indices and served:
+                m.check_status()          # the reference's exceptions for this step's inputs (synchronises)
         return None
 
     criterion._detr_amd_hooks = (criterion.register_forward_pre_hook(before, with_kwargs=True),

@@ -468,19 +468,22 @@ class HungarianMatcher(torch.nn.Module):
                     return found
         return self.match_many([outputs], targets)[0]
 
-    def prefetch(self, outputs_list: Sequence[Dict[str, torch.Tensor]], targets) -> None:
+    def prefetch(self, outputs_list: Sequence[Dict[str, torch.Tensor]], targets, device_indices: bool = False) -> None:
         """Match all of `outputs_list` now, in one `match_many` call, and hand the results out when `forward` is
         called with one of these very output dicts and these very targets (same objects, tensors unchanged since):
         what lets a criterion that calls the matcher once per decoder layer
         (/root/reference/models/detr/loss.py:164-169) run at the speed of one batched call without a change to
         its loop.  A call with anything else is matched on the spot as usual.  `clear_prefetched` drops the
-        results (and the references to the predictions they are keyed by)."""
+        results (and the references to the predictions they are keyed by).
+        `device_indices`: the results are views of a device buffer instead of CPU tensors (no host synchronisation;
+        input errors are then raised by `check_status()`); every expression the reference's losses apply to the
+        indices (detr/loss.py:71-75, 102-103, 124-125) takes them, and gathers with them need no index upload."""
         state = self.__dict__
         state["_prefetched"] = None
         outputs_list = list(outputs_list)
         if not outputs_list:
             return
-        results = self.match_many(outputs_list, targets)
+        results = self.match_many(outputs_list, targets, device_indices=device_indices)
         packed = self._packed          # (what match_many has just made of `targets`: knows whether it is handed them again)
         table = {}
         for o, r in zip(outputs_list, results):

@@ -170,3 +170,33 @@ def test_attach_swaps_auxiliary_assigners_that_then_run_on_the_gpu():
     assert len(got) == 5 and all(torch.equal(a0, b0) and torch.equal(a1, b1) for (a0, a1), (b0, b1) in zip(got, want))
     pos, neg = crit.aux_heads["faster_rcnn"](sets[1], targets)
     assert len(pos) == 5 and len(neg) == 5
+
+
+@pytest.mark.gpu
+def test_attach_with_device_resident_indices():
+    """attach(criterion, device_indices=True): the loop gets device tensors (same values), the expressions the
+    reference's losses apply to them work without an upload, and bad inputs raise when the criterion returns."""
+    import detr_amd
+    from detr_amd import synth
+    from detr_amd.criterion import attach
+
+    wl, sets, targets = synth.make_workload("cfg3_hw", device="cuda", batch=6)
+    want = detr_amd.HungarianMatcher(**wl.matcher_kwargs).match_many(sets, targets)
+    want = [[(a.clone(), b.clone()) for a, b in per] for per in want]
+    crit = LoopCriterion(types.SimpleNamespace(**wl.matcher_kwargs))
+    attach(crit, device_indices=True)
+    assert crit({"model": sets[:6], "first_stage": sets[6:]}, targets) == 7
+    for s, (got, ref) in enumerate(zip(crit.seen, want)):
+        for (g0, g1), (r0, r1) in zip(got, ref):
+            assert g0.device.type == "cuda" and torch.equal(g0.cpu(), r0) and torch.equal(g1.cpu(), r1)
+        # detr/loss.py:71-75, 102-103: permutation index and gathers, all on the device
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(got)])
+        src_idx = torch.cat([src for src, _ in got])
+        picked = sets[s]["pred_boxes"][batch_idx, src_idx]
+        tgt_boxes = torch.cat([t["boxes"][j] for t, (_, j) in zip(targets, got)])
+        assert picked.shape == tgt_boxes.shape == (sum(len(t["labels"]) for t in targets), 4)
+    bad = [{k: v.clone() for k, v in o.items()} for o in sets[:2]]
+    bad[1]["pred_boxes"][2, 7, 3] = float("nan")
+    with pytest.raises(AssertionError):
+        crit({"model": bad}, targets)
+    assert crit({"model": sets[:2]}, targets) == 2          # and the next step is fine again

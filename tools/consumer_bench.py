@@ -2,6 +2,8 @@
 """Time of the criterion's first steps after matching, for all output sets of one step:
 (a) the reference's way: CPU index tuples -> per set permutation index, gathers, [N, N] GIoU
     + diag, dense class map with stock torch ops (loss.py:71-75, 97-125), forward + backward;
+(a') the same stock torch ops handed DEVICE index tuples (match_many(device_indices=True), what
+     detr_amd.criterion.attach(criterion, device_indices=True) serves the loop): no index upload per gather;
 (b) detr_amd.losses on the FlatMatches of match_flat.
 Matching itself is outside both timings."""
 import os
@@ -76,8 +78,10 @@ for o in sets:
     o["pred_boxes"].requires_grad_(True)
 m = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
 tuples = m.match_many(sets, targets)
+dev_tuples = m.match_many(sets, targets, device_indices=True)
 flats = m.match_flat(sets, targets)
 no_object = wl.n_logits - 1
 print(f"{name}: reference-style torch ops {timeit(lambda: reference_way(sets, targets, tuples, no_object)):9.1f} us/step")
+print(f"{name}: the same on device index tuples {timeit(lambda: reference_way(sets, targets, dev_tuples, no_object)):9.1f} us/step")
 print(f"{name}: fused consumers           {timeit(lambda: fused_way(sets, flats, no_object)):9.1f} us/step")
 print(f"{name}: fused, weighted total     {timeit(lambda: fused_total(sets, flats, no_object)):9.1f} us/step")
