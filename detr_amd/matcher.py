@@ -468,7 +468,8 @@ class HungarianMatcher(torch.nn.Module):
                     return found
         return self.match_many([outputs], targets)[0]
 
-    def prefetch(self, outputs_list: Sequence[Dict[str, torch.Tensor]], targets, device_indices: bool = False) -> None:
+    def prefetch(self, outputs_list: Sequence[Dict[str, torch.Tensor]], targets, device_indices: bool = False,
+                 flat: bool = False) -> None:
         """Match all of `outputs_list` now, in one `match_many` call, and hand the results out when `forward` is
         called with one of these very output dicts and these very targets (same objects, tensors unchanged since):
         what lets a criterion that calls the matcher once per decoder layer
@@ -477,25 +478,44 @@ class HungarianMatcher(torch.nn.Module):
         results (and the references to the predictions they are keyed by).
         `device_indices`: the results are views of a device buffer instead of CPU tensors (no host synchronisation;
         input errors are then raised by `check_status()`); every expression the reference's losses apply to the
-        indices (detr/loss.py:71-75, 102-103, 124-125) takes them, and gathers with them need no index upload."""
+        indices (detr/loss.py:71-75, 102-103, 124-125) takes them, and gathers with them need no index upload.
+        `flat` (implies device indices): the launch's `FlatMatches` are kept beside the tuples, for consumers that
+        recognise a served result (`served_flat`) and hand it to the fused kernels of detr_amd.losses."""
         state = self.__dict__
         state["_prefetched"] = None
         outputs_list = list(outputs_list)
         if not outputs_list:
             return
-        results = self.match_many(outputs_list, targets, device_indices=device_indices)
-        packed = self._packed          # (what match_many has just made of `targets`: knows whether it is handed them again)
+        flats = None
+        if flat:
+            flats, results = self.match_flat(outputs_list, targets, with_tuples=True)
+        else:
+            results = self.match_many(outputs_list, targets, device_indices=device_indices)
+        packed = self._packed          # (what the call has just made of `targets`: knows whether it is handed them again)
         table = {}
-        for o, r in zip(outputs_list, results):
+        for k, (o, r) in enumerate(zip(outputs_list, results)):
             l, x = o["pred_logits"], o["pred_boxes"]
-            table[id(o)] = (o, l, x, l._version, x._version, targets, packed, r)
+            table[id(o)] = (o, l, x, l._version, x._version, targets, packed, r, flats[k] if flats else None)
         state["_prefetched"] = table
 
     def clear_prefetched(self) -> None:
         self.__dict__["_prefetched"] = None
 
+    def served_flat(self, outputs, indices) -> Optional["FlatMatches"]:
+        """The `FlatMatches` of `outputs` when `indices` is the very result `prefetch(..., flat=True)` has ready for that
+        output dict (and its prediction boxes are unchanged since); None for anything else -- indices that came from
+        elsewhere (the denoising groups bring their own) or a matcher call that was not served from the prefetch."""
+        ahead = self.__dict__.get("_prefetched")
+        hit = ahead.get(id(outputs)) if ahead else None
+        if hit is None or hit[0] is not outputs or hit[7] is not indices or hit[8] is None:
+            return None
+        x = outputs["pred_boxes"]
+        if x is not hit[2] or x._version != hit[4] or x.dtype != torch.float32:
+            return None
+        return hit[8]
+
     def _prefetch_hit(self, hit, outputs, targets):
-        o, l, x, lv, xv, tg, packed, result = hit
+        o, l, x, lv, xv, tg, packed, result, _ = hit
         if o is not outputs or outputs["pred_logits"] is not l or outputs["pred_boxes"] is not x \
                 or l._version != lv or x._version != xv:
             return None
@@ -843,30 +863,32 @@ class HungarianMatcher(torch.nn.Module):
         return result
 
     @torch.no_grad()
-    def match_flat(self, outputs_list, targets) -> List["FlatMatches"]:
+    def match_flat(self, outputs_list, targets, with_tuples: bool = False):
         """`match_many` for consumers that want flat device-resident indices: one `FlatMatches`
         per output set, no device-to-host copy, no synchronisation (input errors surface through
-        `check_status()`)."""
+        `check_status()`).  `with_tuples`: returns (flat matches, the per-image index tuples of
+        `match_many(device_indices=True)`) -- two views of the same launch's index buffer."""
         S = len(outputs_list)
         if S == 0:
-            return []
+            return ([], []) if with_tuples else []
         outputs_list, targets = self._float32_inputs(outputs_list, targets)
         groups = self._by_class_count(outputs_list)
         if groups is not None:
-            result, statuses = [None] * S, []
+            result, tuples, statuses = [None] * S, [None] * S, []
             for members in groups:
-                part = self.match_flat([outputs_list[i] for i in members], targets)
+                part = self.match_flat([outputs_list[i] for i in members], targets, with_tuples=True)
                 statuses.append(self.last_status)
                 for k, i in enumerate(members):
-                    result[i] = part[k] if part else None
+                    result[i] = part[0][k] if part[0] else None
+                    tuples[i] = part[1][k] if part[1] else []
             if all(r is None for r in result):
-                return []
+                return ([], tuples) if with_tuples else []
             self.last_status = functools.reduce(torch.bitwise_or, [st for st in statuses if st is not None])
-            return result
+            return (result, tuples) if with_tuples else result
         device = outputs_list[0]["pred_logits"].device
         packed = self._packed_for(targets, device)
         if packed.batch == 0:
-            return []
+            return ([], [[] for _ in range(S)]) if with_tuples else []
         out, queries, _, _ = self._launch(outputs_list, packed, flat=True)
         M, sizes = packed.total, packed.sizes
         batch_idx = packed.batch_index
@@ -886,6 +908,8 @@ class HungarianMatcher(torch.nn.Module):
             keep_dev = packed._filled_slots(q)
             result.append(FlatMatches(batch_idx[keep_dev], src[keep_dev], tgt[keep_dev], flat[keep_dev], packed, q,
                                       (out, S), s))
+        if with_tuples:
+            return result, self._split(out, S, M, sizes, queries, packed.offsets_list)
         return result
 
     def check_status(self):

@@ -200,3 +200,81 @@ def test_attach_with_device_resident_indices():
     with pytest.raises(AssertionError):
         crit({"model": bad}, targets)
     assert crit({"model": sets[:2]}, targets) == 2          # and the next step is fine again
+
+
+class BoxLossCriterion(LoopCriterion):
+    """LoopCriterion plus the box loss as the reference's criteria compute it (permutation index, gathers, the
+    [N, N] GIoU matrix and its diagonal: /root/reference/models/detr/loss.py:97-114), restated with stock torch ops."""
+
+    def calc_box_loss(self, outputs, targets, indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        src_idx = torch.cat([src for src, _ in indices])
+        n = max(len(batch_idx), 1)
+        a = outputs["pred_boxes"][batch_idx, src_idx]
+        g = torch.cat([t["boxes"][j] for t, (_, j) in zip(targets, indices)])
+        l1 = (a - g).abs().sum() / n
+
+        def xyxy(b):
+            return torch.cat([b[:, :2] - 0.5 * b[:, 2:], b[:, :2] + 0.5 * b[:, 2:]], -1)
+
+        a, g = xyxy(a), xyxy(g)
+        area_a, area_g = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]), (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
+        wh = (torch.min(a[:, None, 2:], g[:, 2:]) - torch.max(a[:, None, :2], g[:, :2])).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        union = area_a[:, None] + area_g - inter
+        ewh = (torch.max(a[:, None, 2:], g[:, 2:]) - torch.min(a[:, None, :2], g[:, :2])).clamp(min=0)
+        earea = ewh[..., 0] * ewh[..., 1]
+        giou = inter / union - (earea - union) / earea
+        return l1, (1 - torch.diag(giou)).sum() / n
+
+    def forward(self, outputs, targets):
+        self.seen, self.box_losses = [], []
+        for key in ("model", "cdn"):
+            for output in outputs.get(key, []):
+                indices = outputs["cdn_indices"] if key == "cdn" else self.matcher(output, targets)
+                self.seen.append(indices)
+                self.box_losses.append(self.calc_box_loss(output, outputs["cdn_targets"] if key == "cdn" else targets, indices))
+        return sum(5.0 * l1 + 2.0 * g for l1, g in self.box_losses)
+
+
+@pytest.mark.gpu
+def test_attach_with_the_fused_box_loss():
+    """attach(criterion, fused_box_loss=True): calc_box_loss is answered by the fused pair-loss kernel for the sets
+    this matcher served (same values and gradients as the criterion's own method), while indices from elsewhere --
+    the denoising group's -- still go through the criterion's own method."""
+    import detr_amd
+    from detr_amd import losses, synth
+    from detr_amd.criterion import attach, detach
+
+    wl, sets, targets = synth.make_workload("cfg3", device="cuda", batch=5)
+    sets = sets[:3]
+    for o in sets:
+        o["pred_boxes"].requires_grad_(True)
+    cdn = {"pred_logits": sets[0]["pred_logits"].detach().clone(), "pred_boxes": sets[0]["pred_boxes"].detach().clone().requires_grad_(True)}
+    cdn_indices = [(torch.arange(min(3, len(t["labels"])), device="cuda"), torch.arange(min(3, len(t["labels"])), device="cuda"))
+                   for t in targets]
+    outputs = {"model": sets, "cdn": [cdn], "cdn_indices": cdn_indices, "cdn_targets": targets}
+    plain = BoxLossCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs))
+    want = plain(outputs, targets)
+    want_losses = [(a.item(), b.item()) for a, b in plain.box_losses]
+    want_grads = torch.autograd.grad(want, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]])
+
+    crit = BoxLossCriterion(types.SimpleNamespace(**wl.matcher_kwargs))
+    attach(crit, fused_box_loss=True)
+    calls = []
+    inner = losses.matched_box_losses
+    losses.matched_box_losses = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    try:
+        got = crit(outputs, targets)
+    finally:
+        losses.matched_box_losses = inner
+    assert len(calls) == 3                                   # the three matched sets; the denoising set took the own method
+    for (a, b), (wa, wb) in zip(crit.box_losses, want_losses):
+        assert abs(a.item() - wa) <= 1e-5 * max(1.0, abs(wa)) and abs(b.item() - wb) <= 1e-5 * max(1.0, abs(wb))
+    grads = torch.autograd.grad(got, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]])
+    for g, w in zip(grads, want_grads):
+        torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6)
+    assert crit.seen[0][0][0].device.type == "cuda"
+    detach(crit)
+    assert "calc_box_loss" not in crit.__dict__
+    torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-6, atol=1e-6)
