@@ -67,7 +67,7 @@ def aux_head_like(other):
 
 
 def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_heads: bool = True,
-           device_indices: bool = False, fused_box_loss: bool = False) -> HungarianMatcher:
+           device_indices: bool = False, fused_consumers: bool = False) -> HungarianMatcher:
     """Make `criterion` (an instance of one of the reference's Criterion classes, or anything that keeps its
     matcher in ``.matcher`` and is called as ``criterion(outputs, targets)``) use the gfx950 matcher, all sets
     of a step matched in one call.  `aux_heads`: also swap the ATSS / Faster-RCNN assigners a Co-DETR criterion keeps
@@ -75,12 +75,13 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     reference's CPU tensors -- its gathers then need no index upload (the reference's loss expressions on a
     64-image, 6-set step: 12 ms instead of 24 ms) and the host never waits for the matcher; the reference's
     exceptions for bad inputs are raised when the criterion returns (one synchronisation per step, where the
-    reference's criteria synchronise anyway to log ``total_loss.item()``).  `fused_box_loss` (implies device
-    indices): the criterion's ``calc_box_loss(outputs, targets, indices)``
-    (/root/reference/models/detr/loss.py:97-114, the same method in all six families) is answered by the fused
-    pair-loss kernel of :mod:`detr_amd.losses` whenever `indices` is a result this matcher served for `outputs` --
-    same two values, same gradient, O(pairs) instead of the [N, N] GIoU matrix and 2B gathers; indices from elsewhere
-    (the denoising groups') go to the criterion's own method.  Returns the matcher.  Calling it twice on one
+    reference's criteria synchronise anyway to log ``total_loss.item()``).  `fused_consumers` (implies device
+    indices): two methods every one of the six criteria has are answered from the launch's flat index buffer
+    whenever `indices` is a result this matcher served -- ``calc_box_loss(outputs, targets, indices)``
+    (/root/reference/models/detr/loss.py:97-114) by the fused pair-loss kernel of :mod:`detr_amd.losses` (same two
+    values, same gradient, O(pairs) instead of the [N, N] GIoU matrix and 2B gathers) and
+    ``_get_src_permutation_idx(indices)`` (:71-75) by two ready tensors instead of B ``full_like`` calls and two
+    concatenations; indices from elsewhere (the denoising groups') go to the criterion's own methods.  Returns the matcher.  Calling it twice on one
     criterion is harmless."""
     matcher = matcher_like(criterion.matcher)
     criterion.matcher = matcher
@@ -90,20 +91,29 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
             heads[key] = aux_head_like(heads[key])
     if getattr(criterion, "_detr_amd_hooks", None) is not None:
         return matcher
-    device_indices = device_indices or fused_box_loss
-    if fused_box_loss and callable(getattr(criterion, "calc_box_loss", None)):
+    device_indices = device_indices or fused_consumers
+    if fused_consumers and callable(getattr(criterion, "calc_box_loss", None)):
         from . import losses
 
-        own = criterion.calc_box_loss           # the criterion's bound method
+        own_box_loss = criterion.calc_box_loss           # the criterion's bound method
 
         def calc_box_loss(outputs, targets, indices):
             m = criterion.matcher
             flat = m.served_flat(outputs, indices) if isinstance(m, HungarianMatcher) else None
             if flat is None:
-                return own(outputs, targets, indices)
+                return own_box_loss(outputs, targets, indices)
             return losses.matched_box_losses([outputs], [flat])[0]
 
         criterion.calc_box_loss = calc_box_loss       # (an instance attribute in front of the class's method)
+    if fused_consumers and callable(getattr(criterion, "_get_src_permutation_idx", None)):
+        own_permutation = criterion._get_src_permutation_idx
+
+        def _get_src_permutation_idx(indices):
+            m = criterion.matcher
+            flat = m.served_flat_of(indices) if isinstance(m, HungarianMatcher) else None
+            return own_permutation(indices) if flat is None else flat.src_permutation_idx()
+
+        criterion._get_src_permutation_idx = _get_src_permutation_idx
 
     def before(module, args, kwargs):
         outputs = args[0] if args else kwargs.get("outputs")
@@ -112,7 +122,7 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
         if not isinstance(m, HungarianMatcher) or outputs is None or targets is None:
             return None
         m.prefetch(sets_the_loop_will_match(outputs, keys, last_only=not getattr(module, "aux_flag", True)), targets,
-                   device_indices=device_indices, flat=fused_box_loss)
+                   device_indices=device_indices, flat=fused_consumers)
         return None
 
     def after(module, args, kwargs, result):
@@ -136,5 +146,6 @@ def detach(criterion: torch.nn.Module) -> None:
         for h in hooks:
             h.remove()
         criterion._detr_amd_hooks = None
-        if "calc_box_loss" in criterion.__dict__:
-            del criterion.__dict__["calc_box_loss"]       # the class's own method shows again
+        for name in ("calc_box_loss", "_get_src_permutation_idx"):
+            if name in criterion.__dict__:
+                del criterion.__dict__[name]       # the class's own method shows again

@@ -496,10 +496,19 @@ class HungarianMatcher(torch.nn.Module):
         for k, (o, r) in enumerate(zip(outputs_list, results)):
             l, x = o["pred_logits"], o["pred_boxes"]
             table[id(o)] = (o, l, x, l._version, x._version, targets, packed, r, flats[k] if flats else None)
+            if flats:
+                table[("indices", id(r))] = (r, flats[k])
         state["_prefetched"] = table
 
     def clear_prefetched(self) -> None:
         self.__dict__["_prefetched"] = None
+
+    def served_flat_of(self, indices) -> Optional["FlatMatches"]:
+        """The `FlatMatches` behind `indices` when that is the very list `prefetch(..., flat=True)` has served for one
+        of its output sets; None for indices that came from elsewhere."""
+        ahead = self.__dict__.get("_prefetched")
+        hit = ahead.get(("indices", id(indices))) if ahead else None
+        return hit[1] if hit is not None and hit[0] is indices else None
 
     def served_flat(self, outputs, indices) -> Optional["FlatMatches"]:
         """The `FlatMatches` of `outputs` when `indices` is the very result `prefetch(..., flat=True)` has ready for that

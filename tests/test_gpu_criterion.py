@@ -206,9 +206,12 @@ class BoxLossCriterion(LoopCriterion):
     """LoopCriterion plus the box loss as the reference's criteria compute it (permutation index, gathers, the
     [N, N] GIoU matrix and its diagonal: /root/reference/models/detr/loss.py:97-114), restated with stock torch ops."""
 
+    def _get_src_permutation_idx(self, indices):
+        return (torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]),
+                torch.cat([src for src, _ in indices]))
+
     def calc_box_loss(self, outputs, targets, indices):
-        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-        src_idx = torch.cat([src for src, _ in indices])
+        batch_idx, src_idx = self._get_src_permutation_idx(indices)
         n = max(len(batch_idx), 1)
         a = outputs["pred_boxes"][batch_idx, src_idx]
         g = torch.cat([t["boxes"][j] for t, (_, j) in zip(targets, indices)])
@@ -238,8 +241,8 @@ class BoxLossCriterion(LoopCriterion):
 
 
 @pytest.mark.gpu
-def test_attach_with_the_fused_box_loss():
-    """attach(criterion, fused_box_loss=True): calc_box_loss is answered by the fused pair-loss kernel for the sets
+def test_attach_with_the_fused_consumers():
+    """attach(criterion, fused_consumers=True): calc_box_loss is answered by the fused pair-loss kernel for the sets
     this matcher served (same values and gradients as the criterion's own method), while indices from elsewhere --
     the denoising group's -- still go through the criterion's own method."""
     import detr_amd
@@ -260,7 +263,7 @@ def test_attach_with_the_fused_box_loss():
     want_grads = torch.autograd.grad(want, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]])
 
     crit = BoxLossCriterion(types.SimpleNamespace(**wl.matcher_kwargs))
-    attach(crit, fused_box_loss=True)
+    attach(crit, fused_consumers=True)
     calls = []
     inner = losses.matched_box_losses
     losses.matched_box_losses = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
@@ -275,6 +278,17 @@ def test_attach_with_the_fused_box_loss():
     for g, w in zip(grads, want_grads):
         torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6)
     assert crit.seen[0][0][0].device.type == "cuda"
+    # the permutation index of a served result comes from the flat buffer; equal to the loop's own expression
+    own = BoxLossCriterion._get_src_permutation_idx.__get__(crit)
+    matcher = crit.matcher
+    assert "_get_src_permutation_idx" in crit.__dict__
+    matcher.prefetch(sets, targets, device_indices=True, flat=True)
+    served = matcher(sets[1], targets)
+    fast, slow = crit._get_src_permutation_idx(served), own(served)
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
+    foreign = crit._get_src_permutation_idx(cdn_indices)
+    assert torch.equal(foreign[1], torch.cat([s for s, _ in cdn_indices]))
+    matcher.clear_prefetched()
     detach(crit)
-    assert "calc_box_loss" not in crit.__dict__
+    assert "calc_box_loss" not in crit.__dict__ and "_get_src_permutation_idx" not in crit.__dict__
     torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-6, atol=1e-6)

@@ -194,8 +194,8 @@ def test_attach_swaps_the_auxiliary_assigners_of_co_detr(reference):
 
 
 @pytest.mark.parametrize("fam", FAMILIES)
-def test_attach_with_fused_box_loss_wraps_the_real_calc_box_loss(reference, fam):
-    """fused_box_loss=True puts a wrapper in front of the criterion's own calc_box_loss (the same signature in all six
+def test_attach_with_fused_consumers_wraps_the_real_calc_box_loss(reference, fam):
+    """fused_consumers=True puts a wrapper in front of the criterion's own calc_box_loss (the same signature in all six
     families).  Here no fused result exists (the stand-in for the kernels yields index tuples only), so every call
     must fall through to the criterion's own method and the loss must be unchanged."""
     from detr_amd.criterion import attach, detach
@@ -206,8 +206,8 @@ def test_attach_with_fused_box_loss_wraps_the_real_calc_box_loss(reference, fam)
     criterion = losses[fam].Criterion(matcher=matcher_mod.HungarianMatcher("focal", 2.0, 5.0, 2.0), n_cls=n_cls,
                                       cls_loss="focal")
     want = criterion(outputs, targets)
-    matcher = attach(criterion, fused_box_loss=True)
-    assert "calc_box_loss" in criterion.__dict__
+    matcher = attach(criterion, fused_consumers=True)
+    assert "calc_box_loss" in criterion.__dict__ and "_get_src_permutation_idx" in criterion.__dict__
     calls = []
     as_many = _oracle_match_many(matcher, calls)
     matcher.match_flat = lambda outs, tg, with_tuples=False: ([], as_many(outs, tg))
@@ -216,4 +216,4 @@ def test_attach_with_fused_box_loss_wraps_the_real_calc_box_loss(reference, fam)
     torch.testing.assert_close(criterion(outputs, targets), want, rtol=1e-5, atol=1e-6)
     assert calls == [len(outputs["model"]) + len(outputs.get("first_stage", []))]
     detach(criterion)
-    assert "calc_box_loss" not in criterion.__dict__
+    assert "calc_box_loss" not in criterion.__dict__ and "_get_src_permutation_idx" not in criterion.__dict__

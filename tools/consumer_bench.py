@@ -50,7 +50,7 @@ def reference_way(sets, targets, tuples, no_object):
 
 
 def mixed_way(sets, targets, tuples, flats, no_object):
-    """What attach(criterion, device_indices=True, fused_box_loss=True) leaves of the reference's work: the class map by
+    """What attach(criterion, device_indices=True, fused_consumers=True) leaves of the reference's work: the class map by
     stock torch ops on device tuples, the box losses by one fused call per output set."""
     total = 0.0
     for o, indices, f in zip(sets, tuples, flats):

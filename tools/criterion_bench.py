@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""What a criterion in the reference's style gets out of each way of wiring the matcher in: forward + backward of one
+step (all decoder-layer sets) with the loss code left as the reference has it -- a loop over the output sets, one
+matcher call each, permutation index, per-image gathers, the [N, N] GIoU matrix and its diagonal, the dense class
+map, a sigmoid focal classification loss (/root/reference/models/detr/loss.py:71-75, 97-127, 160-183; restated here
+with stock torch ops).
+
+    python tools/criterion_bench.py [workload]
+
+  import swapped         from detr_amd import HungarianMatcher, nothing else
+  attach                 + detr_amd.criterion.attach(criterion): one batched matcher call per step
+  attach, device indices + device_indices=True: the loss code's gathers need no index upload
+  attach, fused consumers + fused_consumers=True: calc_box_loss and _get_src_permutation_idx answered from the flat buffer
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+import detr_amd
+from detr_amd import synth
+from detr_amd.criterion import attach, detach
+
+
+def xyxy(b):
+    return torch.cat([b[:, :2] - 0.5 * b[:, 2:], b[:, :2] + 0.5 * b[:, 2:]], -1)
+
+
+class Criterion(torch.nn.Module):
+    def __init__(self, matcher, n_cls, cls_loss):
+        super().__init__()
+        self.matcher, self.n_cls, self.cls_loss, self.aux_flag = matcher, n_cls, cls_loss, True
+
+    def _get_src_permutation_idx(self, indices):
+        return (torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]),
+                torch.cat([src for src, _ in indices]))
+
+    def calc_box_loss(self, outputs, targets, indices):
+        idx = self._get_src_permutation_idx(indices)
+        n = max(len(idx[0]), 1)
+        a = outputs["pred_boxes"][idx]
+        g = torch.cat([t["boxes"][j] for t, (_, j) in zip(targets, indices)])
+        l1 = F.l1_loss(a, g, reduction="none").sum() / n
+        a, g = xyxy(a), xyxy(g)
+        area_a, area_g = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]), (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
+        wh = (torch.min(a[:, None, 2:], g[:, 2:]) - torch.max(a[:, None, :2], g[:, :2])).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        union = area_a[:, None] + area_g - inter
+        ewh = (torch.max(a[:, None, 2:], g[:, 2:]) - torch.min(a[:, None, :2], g[:, :2])).clamp(min=0)
+        earea = ewh[..., 0] * ewh[..., 1]
+        giou = inter / union - (earea - union) / earea
+        return l1, (1 - torch.diag(giou)).sum() / n
+
+    def calc_cls_loss(self, outputs, targets, indices):
+        idx = self._get_src_permutation_idx(indices)
+        n = max(len(idx[0]), 1)
+        logits = outputs["pred_logits"]
+        target_cls = torch.full(logits.shape[:2], self.n_cls, device=logits.device)
+        target_cls[idx] = torch.cat([t["labels"][j] for t, (_, j) in zip(targets, indices)])
+        if self.cls_loss == "ce":
+            return F.cross_entropy(logits.transpose(1, 2), target_cls)
+        onehot = F.one_hot(target_cls, self.n_cls + 1)[..., :-1].float()
+        p = logits.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
+        p_t = p * onehot + (1 - p) * (1 - onehot)
+        loss = (0.25 * onehot + 0.75 * (1 - onehot)) * ce * (1 - p_t) ** 2
+        return loss.mean(1).sum() / n * logits.shape[1]
+
+    def forward(self, outputs, targets):
+        total = 0.0
+        for output in outputs["model"]:
+            indices = self.matcher(output, targets)
+            l1, giou = self.calc_box_loss(output, targets, indices)
+            total = total + 5.0 * l1 + 2.0 * giou + 2.0 * self.calc_cls_loss(output, targets, indices)
+        return total / len(outputs["model"])
+
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+wl, sets, targets = synth.make_workload(name, device="cuda")
+for o in sets:
+    o["pred_boxes"].requires_grad_(True)
+    o["pred_logits"].requires_grad_(True)
+outputs = {"model": sets}
+pool = [[{k: v[:] for k, v in t.items()} for t in targets] for _ in range(4)]
+
+
+def timeit(criterion, n=30):
+    for k in range(5):
+        criterion(outputs, pool[k & 3]).backward()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        loss = criterion(outputs, pool[k & 3])
+        loss.backward()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3, float(loss.detach())
+
+
+crit = Criterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss)
+print(f"{name}: criterion forward + backward per step (ms), loss value")
+print("  import swapped           %8.2f   %.6f" % timeit(crit))
+attach(crit)
+print("  attach                   %8.2f   %.6f" % timeit(crit))
+detach(crit)
+attach(crit, device_indices=True)
+print("  attach, device indices   %8.2f   %.6f" % timeit(crit))
+detach(crit)
+attach(crit, fused_consumers=True)
+print("  attach, fused consumers  %8.2f   %.6f" % timeit(crit))
