@@ -485,10 +485,16 @@ def main():
         if world == 1 and not args.no_stress:
             stress = stress_roofline(device)
     cost_ms_avg, lap_ms_avg = kernel_times(max(args.steps, 50))
+    # One short untimed region bracketed exactly like the timed one.  The first steps after a device-wide
+    # synchronisation that follows a long unsynchronised run take 90-115 us instead of 73-76 (per-step stamps,
+    # tools/warmcurve.py: steps 2-7 behind the fence, whatever ran before it); a timed region of 20 steps would carry
+    # that one-off as +8 us per step (83-86 us against 75-77 us for every later 20-step region of the same process).
+    timed_region(min(5, args.steps))
     elapsed = timed_region(args.steps)
     gc.collect()
     gc.disable()
     try:
+        timed_region(min(5, args.steps))      # (a full collection empties the interpreter's free lists: refilled here, untimed)
         elapsed_paused = timed_region(args.steps)
     finally:
         gc.enable()
@@ -513,7 +519,7 @@ def main():
                                    f"{len(wl.set_queries) * B} assignment problems per step per GPU",
                        "parallelism": f"dp{world}", "python_gc": "on",
                        "order": f"{args.warmup} warm-up steps, the cost-kernel passes (roofline, roofline_stress), "
-                                f"kernel-event pass ({max(args.steps, 50)} steps), "
+                                f"kernel-event pass ({max(args.steps, 50)} steps), a fenced rehearsal region ({min(5, args.steps)} steps, untimed), "
                                 f"the headline region ({args.steps} steps), the collector-paused region ({args.steps} steps)"},
             "python_gc_paused": {"value": total_images * args.steps / elapsed_paused, "unit": "images/s",
                                  "ms_per_step": 1e3 * elapsed_paused / args.steps},
