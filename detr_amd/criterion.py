@@ -81,7 +81,13 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     (/root/reference/models/detr/loss.py:97-114) by the fused pair-loss kernel of :mod:`detr_amd.losses` (same two
     values, same gradient, O(pairs) instead of the [N, N] GIoU matrix and 2B gathers) and
     ``_get_src_permutation_idx(indices)`` (:71-75) by two ready tensors instead of B ``full_like`` calls and two
-    concatenations; indices from elsewhere (the denoising groups') go to the criterion's own methods.  Returns the matcher.  Calling it twice on one
+    concatenations; indices from elsewhere (the denoising groups') go to the criterion's own methods.
+    ``calc_cls_loss(outputs, targets, indices, ...)`` (:116-133) keeps the criterion's own body -- its class map, its
+    classification loss, its accuracy log -- but is handed the batch as ONE pseudo-image: the packed labels as the
+    only target and one (src, flat target index) pair as the only result, so that its per-image label gathers
+    ``cat([t['labels'][i] for t, (_, i) in zip(targets, indices)])`` are one gather instead of B (this relies on the
+    method touching `targets` and `indices` through that expression and `_get_src_permutation_idx` only, which holds
+    for the six criteria of the reference).  Returns the matcher.  Calling it twice on one
     criterion is harmless."""
     matcher = matcher_like(criterion.matcher)
     criterion.matcher = matcher
@@ -114,6 +120,20 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
             return own_permutation(indices) if flat is None else flat.src_permutation_idx()
 
         criterion._get_src_permutation_idx = _get_src_permutation_idx
+        if callable(getattr(criterion, "calc_cls_loss", None)):
+            own_cls_loss = criterion.calc_cls_loss
+
+            def calc_cls_loss(outputs, targets, indices, *args, **kwargs):
+                m = criterion.matcher
+                flat = m.served_flat(outputs, indices) if isinstance(m, HungarianMatcher) else None
+                if flat is None:
+                    return own_cls_loss(outputs, targets, indices, *args, **kwargs)
+                one_pair = [(flat.src_idx, flat.tgt_flat)]
+                m.register_flat_view(one_pair, flat)        # (its permutation index is the whole batch's, see above)
+                one_image = [{"labels": flat.packed.labels, "boxes": flat.packed.boxes}]
+                return own_cls_loss(outputs, one_image, one_pair, *args, **kwargs)
+
+            criterion.calc_cls_loss = calc_cls_loss
 
     def before(module, args, kwargs):
         outputs = args[0] if args else kwargs.get("outputs")
@@ -146,6 +166,6 @@ def detach(criterion: torch.nn.Module) -> None:
         for h in hooks:
             h.remove()
         criterion._detr_amd_hooks = None
-        for name in ("calc_box_loss", "_get_src_permutation_idx"):
+        for name in ("calc_box_loss", "_get_src_permutation_idx", "calc_cls_loss"):
             if name in criterion.__dict__:
                 del criterion.__dict__[name]       # the class's own method shows again

@@ -510,6 +510,13 @@ class HungarianMatcher(torch.nn.Module):
         hit = ahead.get(("indices", id(indices))) if ahead else None
         return hit[1] if hit is not None and hit[0] is indices else None
 
+    def register_flat_view(self, indices_like, flat: "FlatMatches") -> None:
+        """Make `served_flat_of(indices_like)` answer `flat` until the prefetched results are dropped: for a consumer
+        that hands a criterion an equivalent, cheaper stand-in for a served result (detr_amd.criterion)."""
+        ahead = self.__dict__.get("_prefetched")
+        if ahead is not None:
+            ahead[("indices", id(indices_like))] = (indices_like, flat)
+
     def served_flat(self, outputs, indices) -> Optional["FlatMatches"]:
         """The `FlatMatches` of `outputs` when `indices` is the very result `prefetch(..., flat=True)` has ready for that
         output dict (and its prediction boxes are unchanged since); None for anything else -- indices that came from

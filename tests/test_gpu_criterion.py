@@ -230,14 +230,32 @@ class BoxLossCriterion(LoopCriterion):
         giou = inter / union - (earea - union) / earea
         return l1, (1 - torch.diag(giou)).sum() / n
 
+    n_cls = 2
+
+    def calc_cls_loss(self, outputs, targets, indices, check_acc=False):
+        """The dense class map and a classification loss on it, the way the reference builds them (loss.py:116-127)."""
+        idx = self._get_src_permutation_idx(indices)
+        logits = outputs["pred_logits"]
+        target_cls = torch.full(logits.shape[:2], self.n_cls, device=logits.device)
+        target_cls_o = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, indices)])
+        target_cls[idx] = target_cls_o
+        self.class_maps.append(target_cls)
+        onehot = torch.nn.functional.one_hot(target_cls, self.n_cls + 1)[..., :-1].float()
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, onehot, reduction="sum") / max(len(idx[0]), 1)
+        if check_acc:
+            self.accuracy = (logits[idx].argmax(-1) == target_cls_o).float().mean()
+        return loss
+
     def forward(self, outputs, targets):
-        self.seen, self.box_losses = [], []
+        self.seen, self.box_losses, self.class_maps, total = [], [], [], 0.0
         for key in ("model", "cdn"):
             for output in outputs.get(key, []):
                 indices = outputs["cdn_indices"] if key == "cdn" else self.matcher(output, targets)
+                tg = outputs["cdn_targets"] if key == "cdn" else targets
                 self.seen.append(indices)
-                self.box_losses.append(self.calc_box_loss(output, outputs["cdn_targets"] if key == "cdn" else targets, indices))
-        return sum(5.0 * l1 + 2.0 * g for l1, g in self.box_losses)
+                self.box_losses.append(self.calc_box_loss(output, tg, indices))
+                total = total + self.calc_cls_loss(output, tg, indices, key == "model")
+        return total + sum(5.0 * l1 + 2.0 * g for l1, g in self.box_losses)
 
 
 @pytest.mark.gpu
@@ -253,6 +271,7 @@ def test_attach_with_the_fused_consumers():
     sets = sets[:3]
     for o in sets:
         o["pred_boxes"].requires_grad_(True)
+        o["pred_logits"].requires_grad_(True)
     cdn = {"pred_logits": sets[0]["pred_logits"].detach().clone(), "pred_boxes": sets[0]["pred_boxes"].detach().clone().requires_grad_(True)}
     cdn_indices = [(torch.arange(min(3, len(t["labels"])), device="cuda"), torch.arange(min(3, len(t["labels"])), device="cuda"))
                    for t in targets]
@@ -260,7 +279,8 @@ def test_attach_with_the_fused_consumers():
     plain = BoxLossCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs))
     want = plain(outputs, targets)
     want_losses = [(a.item(), b.item()) for a, b in plain.box_losses]
-    want_grads = torch.autograd.grad(want, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]])
+    want_maps, want_acc = [m.clone() for m in plain.class_maps], plain.accuracy.item()
+    want_grads = torch.autograd.grad(want, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]] + [o["pred_logits"] for o in sets])
 
     crit = BoxLossCriterion(types.SimpleNamespace(**wl.matcher_kwargs))
     attach(crit, fused_consumers=True)
@@ -274,7 +294,11 @@ def test_attach_with_the_fused_consumers():
     assert len(calls) == 3                                   # the three matched sets; the denoising set took the own method
     for (a, b), (wa, wb) in zip(crit.box_losses, want_losses):
         assert abs(a.item() - wa) <= 1e-5 * max(1.0, abs(wa)) and abs(b.item() - wb) <= 1e-5 * max(1.0, abs(wb))
-    grads = torch.autograd.grad(got, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]])
+    # the class maps come out of the criterion's own calc_cls_loss, handed the batch as one pseudo-image
+    assert len(crit.class_maps) == 4 and all(torch.equal(a, b) for a, b in zip(crit.class_maps, want_maps))
+    assert abs(crit.accuracy.item() - want_acc) < 1e-6
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    grads = torch.autograd.grad(got, [o["pred_boxes"] for o in sets] + [cdn["pred_boxes"]] + [o["pred_logits"] for o in sets])
     for g, w in zip(grads, want_grads):
         torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6)
     assert crit.seen[0][0][0].device.type == "cuda"
@@ -290,5 +314,5 @@ def test_attach_with_the_fused_consumers():
     assert torch.equal(foreign[1], torch.cat([s for s, _ in cdn_indices]))
     matcher.clear_prefetched()
     detach(crit)
-    assert "calc_box_loss" not in crit.__dict__ and "_get_src_permutation_idx" not in crit.__dict__
+    assert not {"calc_box_loss", "_get_src_permutation_idx", "calc_cls_loss"} & set(crit.__dict__)
     torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-6, atol=1e-6)

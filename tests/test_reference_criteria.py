@@ -217,3 +217,77 @@ def test_attach_with_fused_consumers_wraps_the_real_calc_box_loss(reference, fam
     assert calls == [len(outputs["model"]) + len(outputs.get("first_stage", []))]
     detach(criterion)
     assert "calc_box_loss" not in criterion.__dict__ and "_get_src_permutation_idx" not in criterion.__dict__
+
+
+def _cpu_flat_stand_in(matcher, calls):
+    """match_flat(with_tuples=True) as the kernels would answer it, from the CPU oracle: FlatMatches whose tensors live on
+    the CPU (batch / source / flat target index per matched pair, the packed labels and boxes) beside the tuples."""
+    from detr_amd.matcher import FlatMatches
+
+    as_many = _oracle_match_many(matcher, calls)
+
+    def match_flat(outputs_list, targets, with_tuples=False):
+        tuples = as_many(outputs_list, targets)
+        sizes = [len(t["labels"]) for t in targets]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        packed = types.SimpleNamespace(labels=torch.cat([t["labels"] for t in targets]),
+                                       boxes=torch.cat([t["boxes"].reshape(-1, 4) for t in targets]),
+                                       total=int(off[-1]), batch=len(targets), max_t=max(sizes))
+        flats = []
+        for o, per_image in zip(outputs_list, tuples):
+            b_idx = torch.cat([torch.full_like(i, b) for b, (i, _) in enumerate(per_image)])
+            src = torch.cat([i for i, _ in per_image])
+            tgt = torch.cat([j for _, j in per_image])
+            flat_t = torch.cat([j + int(off[b]) for b, (_, j) in enumerate(per_image)])
+            flats.append(FlatMatches(b_idx, src, tgt, flat_t, packed, int(o["pred_logits"].shape[1])))
+        return (flats, tuples) if with_tuples else flats
+
+    return match_flat
+
+
+def _torch_pair_losses(outputs_list, flats):
+    """What detr_amd.losses.matched_box_losses computes, with stock torch ops on the flat indices (pairwise, O(pairs))."""
+    result = []
+    for o, f in zip(outputs_list, flats):
+        a, g = o["pred_boxes"][f.batch_idx, f.src_idx], f.packed.boxes[f.tgt_flat]
+        n = float(max(len(f.src_idx), 1))
+        l1 = (a - g).abs().sum() / n
+        a = torch.cat([a[:, :2] - 0.5 * a[:, 2:], a[:, :2] + 0.5 * a[:, 2:]], -1)
+        g = torch.cat([g[:, :2] - 0.5 * g[:, 2:], g[:, :2] + 0.5 * g[:, 2:]], -1)
+        area_a, area_g = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]), (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
+        wh = (torch.min(a[:, 2:], g[:, 2:]) - torch.max(a[:, :2], g[:, :2])).clamp(min=0)
+        inter = wh[:, 0] * wh[:, 1]
+        union = area_a + area_g - inter
+        ewh = (torch.max(a[:, 2:], g[:, 2:]) - torch.min(a[:, :2], g[:, :2])).clamp(min=0)
+        earea = ewh[:, 0] * ewh[:, 1]
+        result.append((l1, (1 - (inter / union - (earea - union) / earea)).sum() / n))
+    return result
+
+
+@pytest.mark.parametrize("aux_flag", [True, False])
+@pytest.mark.parametrize("cls_loss", ["ce", "focal"])
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_fused_consumers_inside_the_references_own_criteria(reference, fam, cls_loss, aux_flag, monkeypatch):
+    """fused_consumers=True with flat results present: the real criteria's calc_box_loss is answered from the flat
+    indices, their own calc_cls_loss runs on the one-pseudo-image stand-in and their own _get_src_permutation_idx is
+    answered for it -- and the total loss equals the unmodified criterion's.  (The fused kernel is stood in for by
+    its stock-torch equivalent, the matching by the CPU oracle.)"""
+    from detr_amd import losses as dm_losses
+    from detr_amd.criterion import attach
+
+    matcher_mod, losses = reference
+    gen = torch.Generator().manual_seed(200 + FAMILIES.index(fam) * 4 + (cls_loss == "ce") + 2 * aux_flag)
+    outputs, targets, n_cls = _inputs(fam, cls_loss, gen)
+    criterion = losses[fam].Criterion(matcher=matcher_mod.HungarianMatcher(cls_loss, 2.0, 5.0, 2.0), n_cls=n_cls,
+                                      cls_loss=cls_loss, aux_flag=aux_flag)
+    want = criterion(outputs, targets)
+    matcher = attach(criterion, fused_consumers=True)
+    calls, fused_calls = [], []
+    matcher.match_flat = _cpu_flat_stand_in(matcher, calls)
+    matcher.check_status = lambda: None
+    monkeypatch.setattr(dm_losses, "matched_box_losses",
+                        lambda outs, flats: (fused_calls.append(len(outs)), _torch_pair_losses(outs, flats))[1])
+    got = criterion(outputs, targets)
+    served = (len(outputs["model"]) if aux_flag else 1) + len(outputs.get("first_stage", []))
+    assert calls == [served] and fused_calls == [1] * served          # every served set took the fused path, no other
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
