@@ -76,7 +76,7 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     64-image, 6-set step: 12 ms instead of 24 ms) and the host never waits for the matcher; the reference's
     exceptions for bad inputs are raised when the criterion returns (one synchronisation per step, where the
     reference's criteria synchronise anyway to log ``total_loss.item()``).  `fused_consumers` (implies device
-    indices): two methods every one of the six criteria has are answered from the launch's flat index buffer
+    indices): three methods every one of the six criteria has work from the launch's flat index buffer
     whenever `indices` is a result this matcher served -- ``calc_box_loss(outputs, targets, indices)``
     (/root/reference/models/detr/loss.py:97-114) by the fused pair-loss kernel of :mod:`detr_amd.losses` (same two
     values, same gradient, O(pairs) instead of the [N, N] GIoU matrix and 2B gathers) and
@@ -87,8 +87,9 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     only target and one (src, flat target index) pair as the only result, so that its per-image label gathers
     ``cat([t['labels'][i] for t, (_, i) in zip(targets, indices)])`` are one gather instead of B (this relies on the
     method touching `targets` and `indices` through that expression and `_get_src_permutation_idx` only, which holds
-    for the six criteria of the reference).  Returns the matcher.  Calling it twice on one
-    criterion is harmless."""
+    for the six criteria of the reference).  The wrappers are instance attributes holding local functions:
+    `detach` the criterion before pickling the object itself (its ``state_dict`` is not affected).  Returns the
+    matcher.  Calling it twice on one criterion is harmless."""
     matcher = matcher_like(criterion.matcher)
     criterion.matcher = matcher
     heads = getattr(criterion, "aux_heads", None)
