@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "detr_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libdetr_match.so")
-SOURCES = ["cost_kernel.hip", "lap_kernel.hip", "pack_kernel.hip", "consumer_kernels.hip", "aux_kernels.hip", "abi.hip"]
+SOURCES = ["cost_kernel.hip", "lap_kernel.hip", "pack_kernel.hip", "consumer_kernels.hip", "cls_loss_kernels.hip", "aux_kernels.hip", "abi.hip"]
 HEADERS = [os.path.join(CSRC, "dm_common.h"), os.path.join(CSRC, "cost_math.h"), os.path.join(ROOT, "include", "detr_match.h")]
 # -ffp-contract=off: every fp32 operation of the cost is rounded separately, as in the
 # reference's elementwise torch ops (hipcc would otherwise fuse a*b+c into an fma).

@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("DETR_AMD_LIB") or os.path.join(_PKG, "libdetr_match.s
 ABI_VERSION = 2
 MAX_SETS_PER_LAUNCH = 16
 NOALLOC_MAX_COST_FLOATS = 8 << 20
+CLS_LOSS_PARTIALS = 4096
 
 OK, E_INVALID_ARG, E_LAUNCH, E_UNSUPPORTED = 0, -1, -2, -3
 NEED_BUFFERS = 1     # dm_match_targets_f32 without pack buffers: nothing launched
@@ -47,6 +48,7 @@ EXPORTS = ["dm_pack_targets", "dm_abi_version", "dm_strerror", "dm_last_hip_erro
            "dm_profile_enable", "dm_profile_read", "dm_match_plan",
            "dm_debug_set_knob",
            "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
+           "dm_focal_loss_f32", "dm_cross_entropy_f32",
            "dm_atss_f32", "dm_frcnn_f32", "dm_frcnn_dense_i64"]
 
 
@@ -95,6 +97,11 @@ def _load():
     lib.dm_pair_loss_backward_f32.argtypes = [isetp, i32, i32, i32, vp, i64p, i64p, vp, vp, vp]
     lib.dm_target_classes_i64.restype = ctypes.c_int
     lib.dm_target_classes_i64.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, ctypes.c_int64, vp]
+    lib.dm_focal_loss_f32.restype = ctypes.c_int
+    lib.dm_focal_loss_f32.argtypes = [vp, vp, ctypes.c_int64, i32, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_int64, i32, vp, vp, vp, vp, vp]
+    lib.dm_cross_entropy_f32.restype = ctypes.c_int
+    lib.dm_cross_entropy_f32.argtypes = [vp, vp, vp, ctypes.c_int64, i32, ctypes.c_int64, vp, vp, vp, vp, vp]
     lib.dm_atss_f32.restype = ctypes.c_int
     lib.dm_atss_f32.argtypes = [isetp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.dm_frcnn_f32.restype = ctypes.c_int

@@ -66,6 +66,51 @@ def aux_head_like(other):
     return other
 
 
+def fuse_cls_criterion(own, seen_devices=None) -> bool:
+    """Put the one-pass kernels of :mod:`detr_amd.losses` in front of `own.forward` when `own` is one of the reference's
+    classification criteria -- ``FocalLoss(alpha, gamma, n_cls)`` (/root/reference/models/detr/loss.py:198-213) or
+    ``CrossEntropy(weight)`` around an ``nn.CrossEntropyLoss`` (:185-195) -- told by their class name and the attributes
+    they keep.  The module object, its buffers and its ``state_dict`` stay as they are: the replacement is an instance
+    attribute ``forward`` (removed by `unfuse_cls_criterion`), which reads the parameters from `own` at every call and
+    hands anything the kernels do not take (CPU or non-float32 tensors, a [B, Q, C] / [B, C, Q] layout that cannot be told
+    because Q == C) to the module's own forward.  Returns whether `own` was recognised."""
+    from . import losses
+
+    if "forward" in own.__dict__:
+        return True
+    name = type(own).__name__
+    own_forward = own.forward
+    if name == "FocalLoss" and all(hasattr(own, a) for a in ("alpha", "gamma", "n_cls")):
+        def forward(inputs, targets, num_boxes):
+            x = losses._class_last(inputs, targets, own.n_cls, None)
+            if x is None or x.shape[-1] != own.n_cls or not losses._takes(x, targets):
+                return own_forward(inputs, targets, num_boxes)
+            if seen_devices is not None:
+                seen_devices.add(x.device)
+            return losses.focal_loss(x, targets, num_boxes, own.alpha, own.gamma)
+    elif name == "CrossEntropy" and isinstance(getattr(own, "criterion", None), torch.nn.CrossEntropyLoss) \
+            and own.criterion.reduction == "mean" and own.criterion.label_smoothing == 0.0:
+        def forward(inputs, targets, num_boxes=None):
+            inner = own.criterion
+            w = inner.weight
+            C = w.shape[0] if w is not None else None
+            x = losses._class_last(inputs, targets, C, None) if C is not None else None
+            if x is None or not losses._takes(x, targets) or w.device != x.device or w.dtype != torch.float32:
+                return own_forward(inputs, targets, num_boxes)
+            if seen_devices is not None:
+                seen_devices.add(x.device)
+            return losses.cross_entropy(x, targets, w, inner.ignore_index)
+    else:
+        return False
+    own.forward = forward          # (an instance attribute in front of the class's method)
+    return True
+
+
+def unfuse_cls_criterion(own) -> None:
+    if isinstance(own, torch.nn.Module) and "forward" in own.__dict__:
+        del own.__dict__["forward"]
+
+
 def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_heads: bool = True,
            device_indices: bool = False, fused_consumers: bool = False) -> HungarianMatcher:
     """Make `criterion` (an instance of one of the reference's Criterion classes, or anything that keeps its
@@ -87,7 +132,11 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     only target and one (src, flat target index) pair as the only result, so that its per-image label gathers
     ``cat([t['labels'][i] for t, (_, i) in zip(targets, indices)])`` are one gather instead of B (this relies on the
     method touching `targets` and `indices` through that expression and `_get_src_permutation_idx` only, which holds
-    for the six criteria of the reference).  The wrappers are instance attributes holding local functions:
+    for the six criteria of the reference).  The criterion's ``cls_criterion`` -- the reference's ``FocalLoss`` or
+    ``CrossEntropy`` module (:185-213) -- gets the one-pass loss-and-gradient kernel of :mod:`detr_amd.losses` in front of
+    its forward (`fuse_cls_criterion`; also for the denoising groups, which bring their own indices); a class value the
+    reference's ``one_hot`` / ``cross_entropy`` would refuse is raised as RuntimeError when the criterion returns.
+    The wrappers are instance attributes holding local functions:
     `detach` the criterion before pickling the object itself (its ``state_dict`` is not affected).  Returns the
     matcher.  Calling it twice on one criterion is harmless."""
     matcher = matcher_like(criterion.matcher)
@@ -99,6 +148,9 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     if getattr(criterion, "_detr_amd_hooks", None) is not None:
         return matcher
     device_indices = device_indices or fused_consumers
+    cls_devices = set()
+    if fused_consumers and isinstance(getattr(criterion, "cls_criterion", None), torch.nn.Module):
+        fuse_cls_criterion(criterion.cls_criterion, cls_devices)
     if fused_consumers and callable(getattr(criterion, "calc_box_loss", None)):
         from . import losses
 
@@ -153,6 +205,13 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
             m.clear_prefetched()
             if device_indices and served:
                 m.check_status()          # the reference's exceptions for this step's inputs (synchronises)
+        if cls_devices:
+            from . import losses
+
+            devices = list(cls_devices)
+            cls_devices.clear()
+            for d in devices:
+                losses.check_cls_status(d)
         return None
 
     criterion._detr_amd_hooks = (criterion.register_forward_pre_hook(before, with_kwargs=True),
@@ -170,3 +229,4 @@ def detach(criterion: torch.nn.Module) -> None:
         for name in ("calc_box_loss", "_get_src_permutation_idx", "calc_cls_loss"):
             if name in criterion.__dict__:
                 del criterion.__dict__[name]       # the class's own method shows again
+        unfuse_cls_criterion(getattr(criterion, "cls_criterion", None))

@@ -5,11 +5,21 @@
     matched_box_loss_total(outputs_list, flats, l1_weight, giou_weight) -> their weighted sum, one scalar
     target_class_maps(flats, no_object)       -> [dense [B, Q] int64 class map] per output set
 
-Both take the `FlatMatches` of ONE `HungarianMatcher.match_flat` call and handle all of its output
+These take the `FlatMatches` of ONE `HungarianMatcher.match_flat` call and handle all of its output
 sets in one launch per operation through the C ABI; nothing synchronises with the host.
+
+The classification loss on the dense class map (the criterion's `cls_criterion`, loss.py:127, 185-242):
+
+    focal_loss(logits, target_cls, num_boxes, alpha, gamma)   FocalLoss / sigmoid_focal_loss, differentiable
+    cross_entropy(logits, target_cls, weight)                 CrossEntropy (nn.CrossEntropyLoss(weight)), differentiable
+    FocalLoss, CrossEntropy                                   modules with the reference's call convention
+    check_cls_status()                                        raises for class values the reference refuses
+
+one pass over the logits per call (loss and gradient together) instead of a dozen elementwise torch kernels
+forward and as many backward.
 """
 import ctypes
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -132,3 +142,185 @@ def target_class_maps(flats: Sequence[FlatMatches], no_object: int) -> List[torc
                                        out.data_ptr(), out.data_ptr() + 8 * S * M, int(no_object), stream)
     _lib.check(rc, "dm_target_classes_i64")
     return maps
+
+
+# ---- the classification loss on the dense class map ------------------------------------------------------------
+
+_cls_partials = {}       # (device index, stream handle) -> float64 workspace of the reduction
+_cls_status = {}         # device index -> int32 word the kernels OR their findings into
+
+
+def _cls_buffers(device):
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    partials = _cls_partials.get((index, stream))
+    if partials is None:
+        partials = _cls_partials[(index, stream)] = torch.empty(_lib.CLS_LOSS_PARTIALS, dtype=torch.float64, device=device)
+    status = _cls_status.get(index)
+    if status is None:
+        status = _cls_status[index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return partials, status, stream
+
+
+def check_cls_status(device=None) -> None:
+    """Raises RuntimeError when a `focal_loss` / `cross_entropy` call on `device` (default: the current one) since the
+    last check met a class value outside the range the reference accepts (its `one_hot` / `cross_entropy` raise for
+    such a value at once; here the row counts as ignored and the finding waits for this call).  Synchronises."""
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    status = _cls_status.get(index)
+    if status is not None and int(status.item()):
+        status.zero_()
+        raise RuntimeError("class values must lie in [0, number of classes] (the last one meaning no object)")
+
+
+def _checked(logits, target_cls):
+    if not logits.is_cuda:
+        raise RuntimeError("detr_amd.losses: the classification loss runs on the GPU (there is no CPU path)")
+    if logits.dtype != torch.float32:
+        raise TypeError(f"logits must be float32, got {logits.dtype}")
+    if target_cls.dtype != torch.int64 or target_cls.device != logits.device:
+        raise TypeError("target_cls must be an int64 tensor on the device of the logits")
+    if logits.dim() < 1 or tuple(logits.shape[:-1]) != tuple(target_cls.shape):
+        raise ValueError(f"logits {tuple(logits.shape)} must be target_cls {tuple(target_cls.shape)} + [C]")
+    x = logits.detach()
+    if not x.is_contiguous() or x.data_ptr() % 16:
+        x = x.contiguous()
+        if x.data_ptr() % 16:
+            x = x.clone()
+    return x, target_cls.contiguous()
+
+
+class _FocalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target_cls, alpha, gamma, scale, ignore_index):
+        x, cls = _checked(logits, target_cls)
+        device = x.device
+        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        out = torch.empty(1, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            partials, status, stream = _cls_buffers(device)
+            rc = lib.dm_focal_loss_f32(x.data_ptr(), cls.data_ptr(), cls.numel(), x.shape[-1], alpha, gamma, scale,
+                                       0 if ignore_index is None else int(ignore_index), 0 if ignore_index is None else 1,
+                                       out.data_ptr(), grad.data_ptr() if grad is not None else None, partials.data_ptr(),
+                                       status.data_ptr(), stream)
+        _lib.check(rc, "dm_focal_loss_f32")
+        ctx.shape = logits.shape
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return (grad * grad_out).view(ctx.shape), None, None, None, None, None
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target_cls, weight, ignore_index):
+        x, cls = _checked(logits, target_cls)
+        device = x.device
+        C = x.shape[-1]
+        if weight is not None:
+            if weight.dtype != torch.float32 or weight.device != device or tuple(weight.shape) != (C,):
+                raise ValueError("weight must be a float32 [C] tensor on the device of the logits")
+            weight = weight.detach().contiguous()
+        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        out = torch.empty(2, dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            partials, status, stream = _cls_buffers(device)
+            rc = lib.dm_cross_entropy_f32(x.data_ptr(), cls.data_ptr(), weight.data_ptr() if weight is not None else None,
+                                          cls.numel(), C, int(ignore_index), out.data_ptr(),
+                                          grad.data_ptr() if grad is not None else None, partials.data_ptr(),
+                                          status.data_ptr(), stream)
+        _lib.check(rc, "dm_cross_entropy_f32")
+        ctx.shape = logits.shape
+        if grad is not None:
+            ctx.save_for_backward(grad, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad, out = ctx.saved_tensors
+        return (grad * (grad_out * out[1])).view(ctx.shape), None, None, None
+
+
+def focal_loss(logits: torch.Tensor, target_cls: torch.Tensor, num_boxes, alpha: float = 0.25, gamma: float = 2.0,
+               ignore_index: Optional[int] = None) -> torch.Tensor:
+    """`FocalLoss.forward` (/root/reference/models/detr/loss.py:198-213 with `sigmoid_focal_loss` :217-242) on
+    class-last `logits [..., C]` and the class map `target_cls [...]` (C = no object): the sum of the focal terms of all
+    logits divided by `num_boxes` -- the reference's `loss.mean(1).sum() / num_boxes * Q`.  `alpha < 0`: no alpha
+    weighting.  `ignore_index`: rows of that class contribute nothing (with -1, the foreground selection of
+    /root/reference/models/co_detr/loss.py:153-166).  A 0-dim tensor; differentiable in `logits`."""
+    return _FocalLoss.apply(logits, target_cls, float(alpha), float(gamma), 1.0 / float(num_boxes), ignore_index)
+
+
+def cross_entropy(logits: torch.Tensor, target_cls: torch.Tensor, weight: Optional[torch.Tensor] = None,
+                  ignore_index: int = -100) -> torch.Tensor:
+    """`CrossEntropy.forward` (/root/reference/models/detr/loss.py:185-195): `nn.CrossEntropyLoss(weight)` with the
+    default 'mean' reduction, on class-last `logits [..., C]`.  A 0-dim tensor; differentiable in `logits`."""
+    return _CrossEntropy.apply(logits, target_cls, weight, ignore_index)
+
+
+def _takes(x, targets) -> bool:
+    """Whether the kernels take these tensors as they are (anything else goes to the caller's own implementation)."""
+    return x.is_cuda and x.dtype == torch.float32 and targets.dtype == torch.int64 and targets.device == x.device
+
+
+def _class_last(inputs, targets, C, channels_first):
+    """`inputs` as a [B, Q, C] tensor, or None when its layout cannot be told: the reference's criteria hand their
+    `cls_criterion` [B, C, Q] (a transposed view, detr/loss.py:127) or [B, Q, C] (co_detr/loss.py:135)."""
+    if channels_first is not None:
+        return inputs.transpose(1, 2) if channels_first else inputs
+    if inputs.dim() != 3 or targets.dim() != 2:
+        return None
+    B, Q = targets.shape
+    if Q == C:
+        return None
+    if tuple(inputs.shape) == (B, Q, C):
+        return inputs
+    if tuple(inputs.shape) == (B, C, Q):
+        return inputs.transpose(1, 2)
+    return None
+
+
+class FocalLoss(torch.nn.Module):
+    """Takes the place of the reference's `FocalLoss(alpha, gamma, n_cls)` as a criterion's `cls_criterion`:
+    `forward(inputs, targets, num_boxes)` with `inputs` [B, n_cls, Q] (/root/reference/models/detr/loss.py:208-213) or
+    [B, Q, n_cls] (/root/reference/models/co_detr/loss.py:272-276) -- `channels_first` says which, None tells them
+    apart by their shape -- and `targets` the [B, Q] class map.  Inputs the kernel does not take (not float32, not on
+    a GPU, a layout that cannot be told) go to `fallback` when one is given."""
+
+    def __init__(self, alpha: float, gamma: float, n_cls: int, channels_first: Optional[bool] = None, fallback=None):
+        super().__init__()
+        self.alpha, self.gamma, self.n_cls, self.channels_first = alpha, gamma, n_cls, channels_first
+        self.fallback = fallback
+
+    def forward(self, inputs, targets, num_boxes):
+        x = _class_last(inputs, targets, self.n_cls, self.channels_first)
+        if x is None or x.shape[-1] != self.n_cls or not _takes(x, targets):
+            if self.fallback is None:
+                raise RuntimeError("detr_amd.losses.FocalLoss: float32 GPU logits of [B, Q, n_cls] or [B, n_cls, Q] expected")
+            return self.fallback(inputs, targets, num_boxes)
+        return focal_loss(x, targets, num_boxes, self.alpha, self.gamma)
+
+
+class CrossEntropy(torch.nn.Module):
+    """Takes the place of the reference's `CrossEntropy(weight)` (/root/reference/models/detr/loss.py:185-195, input
+    [B, C, Q]; /root/reference/models/co_detr/loss.py:249-259, input [B, Q, C])."""
+
+    def __init__(self, weight: Optional[torch.Tensor] = None, channels_first: Optional[bool] = None,
+                 ignore_index: int = -100, fallback=None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else weight.detach().clone().float())
+        self.channels_first, self.ignore_index, self.fallback = channels_first, ignore_index, fallback
+
+    def forward(self, inputs, targets, num_boxes=None):
+        C = self.weight.shape[0] if self.weight is not None else \
+            (inputs.shape[1] if self.channels_first else inputs.shape[-1] if self.channels_first is False else None)
+        x = _class_last(inputs, targets, C, self.channels_first) if C is not None else None
+        if x is None or not _takes(x, targets) or (self.weight is not None and self.weight.device != x.device):
+            if self.fallback is None:
+                raise RuntimeError("detr_amd.losses.CrossEntropy: float32 GPU logits of [B, Q, C] or [B, C, Q] expected")
+            return self.fallback(inputs, targets, num_boxes)
+        return cross_entropy(x, targets, self.weight, self.ignore_index)

@@ -268,6 +268,42 @@ int dm_target_classes_i64(const DmIndexSet *sets, int S, int B, int M, const int
                           int64_t no_object, void *stream);
 
 /*
+ * ---- The classification loss on the dense class map ---------------------------------------------
+ * What the criterion's `cls_criterion` computes from pred_logits and the [B, Q] class map
+ * (/root/reference/models/detr/loss.py:127), in one pass over the logits: the loss and, when grad_out is given,
+ * d loss / d logit for every logit (what autograd hands back for a unit upstream gradient).
+ *   logits      device float[rows][C], contiguous (16-byte aligned for dm_focal_loss_f32), rows = B * Q
+ *   target_cls  device int64[rows]
+ *   partials    device double[DM_CLS_LOSS_PARTIALS]: workspace, overwritten (calls that share it must be ordered)
+ *   status      device int32, bits are OR-ed in: DM_ST_LABEL_RANGE for a class outside the accepted range (the
+ *               reference's one_hot / cross_entropy raise for it); such a row counts as ignored
+ * rows * C < 2^31 (DM_E_UNSUPPORTED beyond).  Fixed-order reductions: bitwise reproducible.
+ *
+ * dm_focal_loss_f32: FocalLoss.forward + sigmoid_focal_loss (loss.py:198-213, 217-242) on
+ * one_hot(target_cls, C + 1)[..., :-1]: class C is "no object" (no positive logit in the row).
+ *   loss_out[0] = scale * sum over all logits; the reference's `loss.mean(1).sum() / num_boxes * Q` is
+ *   scale = 1 / num_boxes.  alpha < 0: no alpha weighting (:238).  With use_ignore, rows whose class is
+ *   ignore_index contribute nothing (the foreground selection of calc_cls_loss_with_ignore,
+ *   /root/reference/models/co_detr/loss.py:161-166).
+ */
+#define DM_CLS_LOSS_PARTIALS 4096
+int dm_focal_loss_f32(const float *logits, const int64_t *target_cls, int64_t rows, int C, float alpha,
+                      float gamma, float scale, int64_t ignore_index, int use_ignore, float *loss_out,
+                      float *grad_out, double *partials, int32_t *status, void *stream);
+
+/*
+ * dm_cross_entropy_f32: CrossEntropy.forward (loss.py:185-195) = nn.CrossEntropyLoss(weight), reduction 'mean':
+ * sum_i w[y_i] * (logsumexp(x_i) - x_i[y_i]) / sum_i w[y_i] over the rows whose class is not ignore_index.
+ *   weight      device float[C] or NULL (all ones)
+ *   loss_out    device float[2]: the loss, and 1 / sum_i w[y_i]
+ *   grad_out    w[y_i] * (softmax(x_i) - onehot(y_i)) -- NOT yet divided by sum_i w[y_i]: the caller scales by
+ *               loss_out[1] (a device value, so that nothing synchronises)
+ */
+int dm_cross_entropy_f32(const float *logits, const int64_t *target_cls, const float *weight, int64_t rows,
+                         int C, int64_t ignore_index, float *loss_out, float *grad_out, double *partials,
+                         int32_t *status, void *stream);
+
+/*
  * ---- Co-DETR auxiliary assigners ---------------------------------------------------------------
  * Replace ATSS.forward and FasterRCNN.forward of
  * /root/reference/models/co_detr/auxiliary_head.py:22-60 and 69-96 for all output sets of a step

@@ -93,6 +93,35 @@ class DtypeCase:
                     cost_giou=self.weights[2])
 
 
+CLS_DIR = os.path.join(GOLDEN_DIR, "cls")
+
+
+class ClsLossCase:
+    """A golden case of tests/golden/cls (made by gen_golden_cls.py): class-last logits [B, Q, C], the dense class map,
+    the parameters of the reference's FocalLoss / CrossEntropy, its loss and the gradient w.r.t. the logits."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(CLS_DIR, name + ".npz"), allow_pickle=False)
+        self.name, self.kind, self.n_cls = name, str(z["kind"]), int(z["n_cls"])
+        self.loss, self.grad = float(z["loss"]), z["grad"]
+        if "from_matcher_case" in z.files:          # inputs live in the matcher golden and its loss golden
+            src = str(z["from_matcher_case"])
+            self.logits = load(src).logits
+            lz = np.load(os.path.join(GOLDEN_DIR, "loss", src + ".npz"), allow_pickle=False)
+            self.target_cls, self.num_boxes = lz["target_cls"], int(lz["num_boxes"])
+        else:
+            self.logits, self.target_cls = z["logits"], z["target_cls"]
+            self.num_boxes = int(z["num_boxes"]) if "num_boxes" in z.files else 1
+        self.alpha = float(z["alpha"]) if "alpha" in z.files else None
+        self.gamma = float(z["gamma"]) if "gamma" in z.files else None
+        self.weight = z["weight"] if "weight" in z.files else None
+        self.ignore_index = int(z["ignore_index"]) if "ignore_index" in z.files else None
+
+
+def cls_case_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(CLS_DIR, "*.npz")))
+
+
 def dtype_case_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(DTYPE_DIR, "*.npz")))
 

@@ -316,3 +316,114 @@ def test_attach_with_the_fused_consumers():
     detach(crit)
     assert not {"calc_box_loss", "_get_src_permutation_idx", "calc_cls_loss"} & set(crit.__dict__)
     torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-6, atol=1e-6)
+
+
+class FocalLoss(torch.nn.Module):
+    """The reference's classification criterion of that name, restated with stock torch ops
+    (/root/reference/models/detr/loss.py:198-213, 217-242): input [B, n_cls, Q]."""
+
+    def __init__(self, alpha, gamma, n_cls):
+        super().__init__()
+        self.alpha, self.gamma, self.n_cls = alpha, gamma, n_cls
+
+    def forward(self, inputs, targets, num_boxes):
+        F = torch.nn.functional
+        inputs = inputs.transpose(1, 2)
+        onehot = F.one_hot(targets, self.n_cls + 1)[:, :, :-1].float()
+        prob = inputs.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(inputs, onehot, reduction="none")
+        p_t = prob * onehot + (1 - prob) * (1 - onehot)
+        loss = (self.alpha * onehot + (1 - self.alpha) * (1 - onehot)) * ce * ((1 - p_t) ** self.gamma)
+        return loss.mean(1).sum() / num_boxes * inputs.shape[1]
+
+
+class CrossEntropy(torch.nn.Module):
+    """/root/reference/models/detr/loss.py:185-195."""
+
+    def __init__(self, weight):
+        super().__init__()
+        self.criterion = torch.nn.CrossEntropyLoss(weight=weight)
+
+    def forward(self, inputs, targets, num_boxes):
+        return self.criterion(inputs, targets)
+
+
+class ClsCriterion(BoxLossCriterion):
+    """BoxLossCriterion with the classification loss behind a `cls_criterion` module, called as the reference's
+    calc_cls_loss calls it (loss.py:127)."""
+
+    def __init__(self, matcher, cls_criterion, n_cls):
+        super().__init__(matcher)
+        self.cls_criterion, self.n_cls = cls_criterion, n_cls
+
+    def calc_cls_loss(self, outputs, targets, indices, check_acc=False):
+        idx = self._get_src_permutation_idx(indices)
+        logits = outputs["pred_logits"]
+        target_cls = torch.full(logits.shape[:2], self.n_cls, device=logits.device)
+        target_cls[idx] = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, indices)])
+        self.class_maps.append(target_cls)
+        return self.cls_criterion(logits.transpose(1, 2), target_cls, max(len(idx[0]), 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["focal", "ce"])
+def test_fused_consumers_front_the_classification_criterion(kind):
+    """attach(criterion, fused_consumers=True) puts the one-pass loss-and-gradient kernel in front of the criterion's
+    FocalLoss / CrossEntropy module: same loss, same gradients w.r.t. logits and boxes, for the matched sets and the
+    denoising group; the module itself (and its state_dict) stays."""
+    import detr_amd
+    from detr_amd import losses, synth
+    from detr_amd.criterion import attach, detach
+
+    wl, sets, targets = synth.make_workload("cfg1" if kind == "ce" else "cfg3", device="cuda", batch=5)
+    sets = sets[:3]
+    n_cls = wl.n_label_classes
+    for o in sets:
+        o["pred_boxes"].requires_grad_(True)
+        o["pred_logits"].requires_grad_(True)
+    cdn = {"pred_logits": sets[0]["pred_logits"].detach().clone().requires_grad_(True),
+           "pred_boxes": sets[0]["pred_boxes"].detach().clone().requires_grad_(True)}
+    cdn_indices = [(torch.arange(min(3, len(t["labels"])), device="cuda"), torch.arange(min(3, len(t["labels"])), device="cuda"))
+                   for t in targets]
+    outputs = {"model": sets, "cdn": [cdn], "cdn_indices": cdn_indices, "cdn_targets": targets}
+    leaves = [o["pred_logits"] for o in sets] + [cdn["pred_logits"]] + [o["pred_boxes"] for o in sets]
+
+    def make():
+        if kind == "focal":
+            return FocalLoss(0.25, 2.0, n_cls)
+        w = torch.ones(n_cls + 1)
+        w[-1] = 0.1
+        return CrossEntropy(w).cuda()
+
+    plain = ClsCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), make(), n_cls)
+    want = plain(outputs, targets)
+    want_grads = torch.autograd.grad(want, leaves)
+
+    crit = ClsCriterion(types.SimpleNamespace(**wl.matcher_kwargs), make(), n_cls)
+    keys = sorted(crit.state_dict())
+    attach(crit, fused_consumers=True)
+    assert "forward" in crit.cls_criterion.__dict__ and sorted(crit.state_dict()) == keys
+    calls = []
+    name = "focal_loss" if kind == "focal" else "cross_entropy"
+    inner = getattr(losses, name)
+    setattr(losses, name, lambda *a, **k: (calls.append(1), inner(*a, **k))[1])
+    try:
+        got = crit(outputs, targets)
+    finally:
+        setattr(losses, name, inner)
+    assert len(calls) == 4                       # three matched sets and the denoising set
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    for g, w in zip(torch.autograd.grad(got, leaves), want_grads):
+        torch.testing.assert_close(g, w, rtol=5e-5, atol=2e-6 * float(w.abs().max()))
+    # a class value the reference's one_hot / cross_entropy refuses: raised when the criterion returns
+    bad = [dict(t) for t in targets]
+    k = next(i for i, t in enumerate(bad) if len(t["labels"]))
+    bad[k]["labels"] = bad[k]["labels"].clone()
+    outputs_bad = dict(outputs, cdn_targets=bad)
+    bad[k]["labels"][0] = n_cls + 3
+    with pytest.raises(RuntimeError):
+        crit(outputs_bad, targets)
+    torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-5, atol=1e-5)     # the next step is fine again
+    detach(crit)
+    assert "forward" not in crit.cls_criterion.__dict__
+    torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-6, atol=1e-6)

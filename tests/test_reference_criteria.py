@@ -291,3 +291,40 @@ def test_fused_consumers_inside_the_references_own_criteria(reference, fam, cls_
     served = (len(outputs["model"]) if aux_flag else 1) + len(outputs.get("first_stage", []))
     assert calls == [served] and fused_calls == [1] * served          # every served set took the fused path, no other
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+
+    # the classification criterion: its forward is fronted by the one-pass loss (stood in for by stock torch ops on the
+    # class-last view it is handed); every family's layout -- [B, C, Q], co_detr [B, Q, C] -- must arrive class-last
+    assert "forward" in criterion.cls_criterion.__dict__
+    cls_calls = []
+
+    def focal_stand_in(x, cls, num_boxes, alpha, gamma, ignore_index=None):
+        assert tuple(x.shape) == tuple(cls.shape) + (n_cls,)
+        cls_calls.append("focal")
+        onehot = torch.nn.functional.one_hot(cls, n_cls + 1)[..., :-1].float()
+        p = x.sigmoid()
+        ce = torch.nn.functional.binary_cross_entropy_with_logits(x, onehot, reduction="none")
+        p_t = p * onehot + (1 - p) * (1 - onehot)
+        return ((alpha * onehot + (1 - alpha) * (1 - onehot)) * ce * (1 - p_t) ** gamma).sum() / num_boxes
+
+    def ce_stand_in(x, cls, weight=None, ignore_index=-100):
+        assert tuple(x.shape) == tuple(cls.shape) + (n_cls + 1,)
+        cls_calls.append("ce")
+        return torch.nn.functional.cross_entropy(x.reshape(-1, x.shape[-1]), cls.reshape(-1), weight=weight,
+                                                 ignore_index=ignore_index)
+
+    monkeypatch.setattr(dm_losses, "_takes", lambda x, t: True)
+    monkeypatch.setattr(dm_losses, "focal_loss", focal_stand_in)
+    monkeypatch.setattr(dm_losses, "cross_entropy", ce_stand_in)
+    monkeypatch.setattr(dm_losses, "check_cls_status", lambda device=None: None)
+    calls.clear()
+    torch.testing.assert_close(criterion(outputs, targets), want, rtol=1e-5, atol=1e-6)
+    # every classification loss of the step went through it: the served sets and the denoising groups
+    n_dn = sum(len(outputs.get(k, [])) for k in ("cdn", "noised")) if aux_flag else sum(1 for k in ("cdn", "noised") if k in outputs)
+    assert cls_calls == ["ce" if cls_loss == "ce" else "focal"] * len(cls_calls) and len(cls_calls) >= served
+    assert len(cls_calls) == served + n_dn, (fam, len(cls_calls), served, n_dn)
+    from detr_amd.criterion import detach
+
+    detach(criterion)
+    assert "forward" not in criterion.cls_criterion.__dict__
+    state = criterion.state_dict()
+    assert all(".fallback" not in k for k in state)

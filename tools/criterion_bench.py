@@ -10,7 +10,9 @@ with stock torch ops).
   import swapped         from detr_amd import HungarianMatcher, nothing else
   attach                 + detr_amd.criterion.attach(criterion): one batched matcher call per step
   attach, device indices + device_indices=True: the loss code's gathers need no index upload
-  attach, fused consumers + fused_consumers=True: calc_box_loss and _get_src_permutation_idx answered from the flat buffer
+  attach, fused consumers + fused_consumers=True: calc_box_loss and _get_src_permutation_idx answered from the flat buffer,
+                         calc_cls_loss on one pseudo-image, the classification criterion fronted by the one-pass kernel
+                         (the line before it: the same with the criterion's own FocalLoss / CrossEntropy left in place)
 """
 import os
 import sys
@@ -22,17 +24,48 @@ import torch.nn.functional as F
 
 import detr_amd
 from detr_amd import synth
-from detr_amd.criterion import attach, detach
+from detr_amd.criterion import attach, detach, unfuse_cls_criterion
 
 
 def xyxy(b):
     return torch.cat([b[:, :2] - 0.5 * b[:, 2:], b[:, :2] + 0.5 * b[:, 2:]], -1)
 
 
+class FocalLoss(torch.nn.Module):              # /root/reference/models/detr/loss.py:198-213, 217-242
+    def __init__(self, alpha, gamma, n_cls):
+        super().__init__()
+        self.alpha, self.gamma, self.n_cls = alpha, gamma, n_cls
+
+    def forward(self, inputs, targets, num_boxes):
+        inputs = inputs.transpose(1, 2)
+        onehot = F.one_hot(targets, self.n_cls + 1)[:, :, :-1].float()
+        prob = inputs.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(inputs, onehot, reduction="none")
+        p_t = prob * onehot + (1 - prob) * (1 - onehot)
+        loss = ce * ((1 - p_t) ** self.gamma)
+        loss = (self.alpha * onehot + (1 - self.alpha) * (1 - onehot)) * loss
+        return loss.mean(1).sum() / num_boxes * inputs.shape[1]
+
+
+class CrossEntropy(torch.nn.Module):           # /root/reference/models/detr/loss.py:185-195
+    def __init__(self, weight):
+        super().__init__()
+        self.criterion = torch.nn.CrossEntropyLoss(weight=weight)
+
+    def forward(self, inputs, targets, num_boxes):
+        return self.criterion(inputs, targets)
+
+
 class Criterion(torch.nn.Module):
     def __init__(self, matcher, n_cls, cls_loss):
         super().__init__()
         self.matcher, self.n_cls, self.cls_loss, self.aux_flag = matcher, n_cls, cls_loss, True
+        if cls_loss == "ce":
+            weight = torch.ones(n_cls + 1)
+            weight[-1] = 0.1
+            self.cls_criterion = CrossEntropy(weight)
+        else:
+            self.cls_criterion = FocalLoss(0.25, 2.0, n_cls)
 
     def _get_src_permutation_idx(self, indices):
         return (torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)]),
@@ -60,14 +93,7 @@ class Criterion(torch.nn.Module):
         logits = outputs["pred_logits"]
         target_cls = torch.full(logits.shape[:2], self.n_cls, device=logits.device)
         target_cls[idx] = torch.cat([t["labels"][j] for t, (_, j) in zip(targets, indices)])
-        if self.cls_loss == "ce":
-            return F.cross_entropy(logits.transpose(1, 2), target_cls)
-        onehot = F.one_hot(target_cls, self.n_cls + 1)[..., :-1].float()
-        p = logits.sigmoid()
-        ce = F.binary_cross_entropy_with_logits(logits, onehot, reduction="none")
-        p_t = p * onehot + (1 - p) * (1 - onehot)
-        loss = (0.25 * onehot + 0.75 * (1 - onehot)) * ce * (1 - p_t) ** 2
-        return loss.mean(1).sum() / n * logits.shape[1]
+        return self.cls_criterion(logits.transpose(1, 2), target_cls, n)
 
     def forward(self, outputs, targets):
         total = 0.0
@@ -99,7 +125,7 @@ def timeit(criterion, n=30):
     return (time.perf_counter() - t0) / n * 1e3, float(loss.detach())
 
 
-crit = Criterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss)
+crit = Criterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss).cuda()
 print(f"{name}: criterion forward + backward per step (ms), loss value")
 print("  import swapped           %8.2f   %.6f" % timeit(crit))
 attach(crit)
@@ -107,6 +133,10 @@ print("  attach                   %8.2f   %.6f" % timeit(crit))
 detach(crit)
 attach(crit, device_indices=True)
 print("  attach, device indices   %8.2f   %.6f" % timeit(crit))
+detach(crit)
+attach(crit, fused_consumers=True)
+unfuse_cls_criterion(crit.cls_criterion)
+print("  fused, own class loss    %8.2f   %.6f" % timeit(crit))
 detach(crit)
 attach(crit, fused_consumers=True)
 print("  attach, fused consumers  %8.2f   %.6f" % timeit(crit))
