@@ -40,80 +40,147 @@ struct FocalParams {
     int use_ignore;
 };
 
-// One logit x of a row whose class is `positive` (t = 1) or not (t = 0): sigmoid_focal_loss (loss.py:233-240) in the
-// reference's own operation order, and d loss / d x as torch autograd derives it from those operations.
+// What the class map says about a row, in 32 bits: the class (0 .. C, C = no object), or one of two codes.
+constexpr int ROW_IGNORED = -1;     // contributes nothing
+constexpr int ROW_BAD = -2;         // a class the reference's one_hot refuses: contributes nothing, and is reported
+
+__device__ __forceinline__ int row_code(int64_t label, unsigned C, const FocalParams &fp)
+{
+    if (fp.use_ignore && label == fp.ignore_index) return ROW_IGNORED;
+    if (label < 0 || label > (int64_t)C) return ROW_BAD;
+    return (int)label;
+}
+
+// One logit x of a row whose class is `positive` (t = 1) or not (t = 0): sigmoid_focal_loss (loss.py:233-240) and
+// d loss / d x as torch autograd derives it from those operations.  With z = -x for the positive logit and z = x for
+// the others, the reference's terms are functions of z alone: 1 - p_t = sigmoid(z) and
+// binary_cross_entropy_with_logits = softplus(z), so that
+//     loss = alpha_t * softplus(z) * sigmoid(z)^gamma,
+//     d loss / d z = alpha_t * sigmoid(z)^(gamma - 1) * sigmoid(z) * (sigmoid(z) + gamma * softplus(z) * (1 - sigmoid(z)))
+// and d loss / d x is that with the sign of dz/dx.  One hardware exponential serves both: with e = exp(-|z|),
+// sigmoid(z) = 1 / (1 + e) or e / (1 + e) (no cancellation in 1 - sigmoid) and softplus(z) = max(z, 0) + log1p(e).
+// (v_exp_f32 / v_log_f32 / v_rcp_f32 are good to about 1e-6 relative, an order of magnitude inside the tolerance the
+// loss is held to; with the library's expf / log1pf / division the kernel is bound by their instruction count, not by
+// memory.)  No branches: the terms of a quad run interleaved.
 template <bool GAMMA2>
 __device__ __forceinline__ float focal_term(float x, bool positive, const FocalParams &fp, float *grad)
 {
-    const float p = 1.0f / (1.0f + expf(-x));                                // prob = inputs.sigmoid()
-    // binary_cross_entropy_with_logits: softplus(-x) for t = 1, softplus(x) for t = 0
-    const float z = positive ? -x : x;
-    const float ce = fmaxf(z, 0.0f) + log1pf(expf(-fabsf(x)));
-    const float q = 1.0f - p;
-    const float base = positive ? q : 1.0f - q;                               // 1 - p_t, p_t = p t + (1 - p)(1 - t)
-    float m, dm;                                                              // (1 - p_t) ** gamma and its derivative in base
-    if (GAMMA2) {
-        m = base * base;
-        dm = 2.0f * base;
-    } else {
-        m = powf(base, fp.gamma);
-        dm = fp.gamma == 0.0f ? 0.0f : fp.gamma * powf(base, fp.gamma - 1.0f);      // (torch: no gradient through x ** 0)
-    }
+    constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+    const unsigned flip = positive ? 0x80000000u : 0u;
+    const float z = __uint_as_float(__float_as_uint(x) ^ flip);
+    const float e = __builtin_amdgcn_exp2f(-fabsf(z) * LOG2E);
+    const float one_e = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(one_e);
+    const float er = e * r;
+    const bool up = z >= 0.0f;
+    const float sg = up ? r : er;                                             // sigmoid(z) = 1 - p_t
+    const float co = up ? er : r;                                             // 1 - sigmoid(z)
+    // log1p(e) = log(1 + e) + the part of e that the rounding of 1 + e dropped, over 1 + e: exact to first order for
+    // every e (a tiny e gives log(1) + e), without a branch
+    const float l1p = __builtin_amdgcn_logf(one_e) * LN2 + (e - (one_e - 1.0f)) * r;
+    const float sp = __builtin_fmaxf(z, 0.0f) + l1p;                          // softplus(z)
     const float a_t = fp.alpha >= 0.0f ? (positive ? fp.alpha : 1.0f - fp.alpha) : 1.0f;
-    // d ce / d x = p - t;  d base / d x = -(2 t - 1) p (1 - p)
-    const float dbase = positive ? -(p * q) : p * q;
-    *grad = a_t * ((p - (positive ? 1.0f : 0.0f)) * m + ce * (dm * dbase)) * fp.scale;
-    return a_t * (ce * m);
+    float m, slope;                                                           // sigmoid^gamma, d (softplus * sigmoid^gamma) / dz
+    if (GAMMA2) {
+        m = sg * sg;
+        const float u = sp * co;
+        slope = m * (sg + (u + u));
+    } else {
+        m = powf(sg, fp.gamma);
+        // (torch: no gradient through x ** 0)
+        const float dm = fp.gamma == 0.0f ? 0.0f : fp.gamma * powf(sg, fp.gamma - 1.0f);
+        slope = sg * m + sp * (dm * (sg * co));
+    }
+    *grad = __uint_as_float(__float_as_uint((a_t * fp.scale) * slope) ^ flip);
+    return a_t * (sp * m);
 }
 
-// Elementwise over the [rows, C] logits, four consecutive elements per thread and trip (one 16-byte load, one
-// 16-byte store); the row of an element is looked up in the class map.
-template <bool GAMMA2>
+// Elementwise over the [rows, C] logits in quads of four consecutive elements (one 16-byte load, one 16-byte store).
+// With two or more classes a quad lies in at most two rows, whose classes are requested together with the logits;
+// ONE_CLASS: every element is a row of its own.  A thread requests the logits and classes of FOCAL_QUADS quads before
+// it computes on any of them (at 8 TB/s and ~2 us of memory latency some 16 MB have to be in flight, twice what one
+// 16-byte load per lane of a full chip holds), and walks from quad to quad by additions: the kernel is close to being
+// bound by its instruction count (about 50 per logit), a division per quad would show.  The up to three logits behind
+// the last whole quad are handled by the first threads of the first workgroup.
+constexpr int FOCAL_QUADS = 2;
+
+template <bool GAMMA2, bool ONE_CLASS>
 __global__ __launch_bounds__(CLS_THREADS) void focal_loss_kernel(const float *__restrict__ x, const int64_t *__restrict__ cls,
-                                                                 const unsigned n, const unsigned C, const FocalParams fp,
-                                                                 float *__restrict__ grad, double *__restrict__ partials,
-                                                                 int32_t *__restrict__ status)
+                                                                 const unsigned n, const unsigned C, const unsigned rows,
+                                                                 const FocalParams fp, float *__restrict__ grad,
+                                                                 double *__restrict__ partials, int32_t *__restrict__ status)
 {
     __shared__ double lds[CLS_THREADS / 64];
     float acc = 0.0f;
     bool bad = false;
-    const unsigned chunks = (n + 3) >> 2;
-    for (unsigned i = blockIdx.x * CLS_THREADS + threadIdx.x; i < chunks; i += gridDim.x * CLS_THREADS) {
-        const unsigned e0 = i << 2;
-        const bool whole = e0 + 4 <= n;
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (whole) {
-            const float4 t = reinterpret_cast<const float4 *>(x)[i];
-            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-        } else {
-            for (unsigned k = 0; e0 + k < n; ++k) v[k] = x[e0 + k];
-        }
-        unsigned row = e0 / C, c = e0 - row * C;
-        int64_t label = cls[row];
-        float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        float part = 0.0f;
+    const unsigned quads = n >> 2;                                   // whole quads
+    const unsigned stride = gridDim.x * CLS_THREADS;
+    // (row, column) of a quad's first element, advanced by `stride` quads at a time
+    const unsigned step_row = (stride << 2) / C, step_col = (stride << 2) - step_row * C;      // wave-uniform
+    unsigned i0 = blockIdx.x * CLS_THREADS + threadIdx.x;
+    unsigned row = (i0 << 2) / C, col = (i0 << 2) - row * C;
+    auto advance = [&](unsigned &r, unsigned &c) {
+        c += step_col;
+        const bool over = c >= C;
+        c = over ? c - C : c;
+        r += step_row + (over ? 1u : 0u);
+    };
+    for (; i0 < quads; i0 += FOCAL_QUADS * stride) {
+        float v[FOCAL_QUADS][4];
+        int64_t label[FOCAL_QUADS][ONE_CLASS ? 4 : 2];
+        unsigned c0[FOCAL_QUADS];
+        // requests
 #pragma unroll
-        for (unsigned k = 0; k < 4; ++k) {
-            if (e0 + k < n) {
-                const bool ignored = fp.use_ignore && label == fp.ignore_index;
-                if (!ignored) {
-                    if (label < 0 || label > (int64_t)C) bad = true;       // one_hot(targets, n_cls + 1) refuses these
-                    part += focal_term<GAMMA2>(v[k], label == (int64_t)c, fp, &g[k]);
-                }
-                if (++c == C && e0 + k + 1 < n) {
-                    c = 0;
-                    label = cls[++row];
+        for (int u = 0; u < FOCAL_QUADS; ++u) {
+            const unsigned i = i0 + u * stride;
+            c0[u] = col;
+            if (i < quads) {
+                const float4 t = reinterpret_cast<const float4 *>(x)[i];
+                v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+                if (ONE_CLASS) {
+#pragma unroll
+                    for (unsigned k = 0; k < 4; ++k) label[u][k] = cls[(i << 2) + k];
+                } else {
+                    label[u][0] = cls[row];
+                    label[u][1] = cls[min(row + 1, rows - 1)];
                 }
             }
+            if (!ONE_CLASS) advance(row, col);
         }
-        acc += part;
-        if (grad) {
-            if (whole) {
-                reinterpret_cast<float4 *>(grad)[i] = make_float4(g[0], g[1], g[2], g[3]);
-            } else {
-                for (unsigned k = 0; e0 + k < n; ++k) grad[e0 + k] = g[k];
+        // arithmetic
+#pragma unroll
+        for (int u = 0; u < FOCAL_QUADS; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i < quads) {
+                int code[ONE_CLASS ? 4 : 2];
+#pragma unroll
+                for (int j = 0; j < (ONE_CLASS ? 4 : 2); ++j) code[j] = row_code(label[u][j], C, fp);
+                float g[4];
+#pragma unroll
+                for (unsigned k = 0; k < 4; ++k) {
+                    const bool wrapped = !ONE_CLASS && c0[u] + k >= C;              // (c0 + 3 < 2 C for C >= 2)
+                    const int row_class = ONE_CLASS ? code[k] : (wrapped ? code[1] : code[0]);
+                    const unsigned column = ONE_CLASS ? 0u : (wrapped ? c0[u] + k - C : c0[u] + k);
+                    const float term = focal_term<GAMMA2>(v[u][k], row_class == (int)column, fp, &g[k]);
+                    const bool counts = row_class >= 0;
+                    acc += counts ? term : 0.0f;
+                    g[k] = counts ? g[k] : 0.0f;
+                    bad |= row_class == ROW_BAD;
+                }
+                if (grad) reinterpret_cast<float4 *>(grad)[i] = make_float4(g[0], g[1], g[2], g[3]);
             }
         }
+    }
+    // the logits behind the last whole quad
+    const unsigned e = (quads << 2) + threadIdx.x;
+    if (blockIdx.x == 0 && e < n) {
+        const unsigned r = e / C;
+        const int row_class = row_code(cls[r], C, fp);
+        float g;
+        const float term = focal_term<GAMMA2>(x[e], row_class == (int)(e - r * C), fp, &g);
+        if (row_class >= 0) acc += term;
+        if (grad) grad[e] = row_class >= 0 ? g : 0.0f;
+        bad |= row_class == ROW_BAD;
     }
     if (bad) dm::raise_status(status, DM_ST_LABEL_RANGE);
     const double total = block_sum((double)acc, lds);
@@ -121,8 +188,10 @@ __global__ __launch_bounds__(CLS_THREADS) void focal_loss_kernel(const float *__
 }
 
 // Weighted cross entropy (nn.CrossEntropyLoss(weight), reduction 'mean'): L lanes share a row (L a power of two up to
-// 64, consecutive lanes read consecutive logits).  Three passes over the row -- maximum, sum of exponentials,
-// gradient -- of which the second and third find the row in the cache.
+// 64, consecutive lanes read consecutive logits).  KEEP: a lane's share of the row is at most four logits and stays in
+// registers -- read once, exponentials taken once (softmax = exp(x - max) / sum serves loss and gradient); otherwise
+// (more than 256 classes) the row is walked three times, the second and third time out of the cache.
+template <bool KEEP>
 __global__ __launch_bounds__(CLS_THREADS) void cross_entropy_kernel(const float *__restrict__ x, const int64_t *__restrict__ cls,
                                                                     const float *__restrict__ weight, const unsigned rows,
                                                                     const unsigned C, const unsigned L,
@@ -132,6 +201,7 @@ __global__ __launch_bounds__(CLS_THREADS) void cross_entropy_kernel(const float 
     __shared__ double lds[CLS_THREADS / 64];
     const unsigned sub = threadIdx.x & (L - 1);
     const unsigned rows_per_block = CLS_THREADS / L;
+    constexpr float LOG2E = 1.4426950408889634f;
     float num = 0.0f, den = 0.0f;
     bool bad = false;
     // every lane of a row group runs the same trips (the shuffles below need all of its lanes)
@@ -139,13 +209,30 @@ __global__ __launch_bounds__(CLS_THREADS) void cross_entropy_kernel(const float 
         const unsigned row = r0 + threadIdx.x / L;
         const bool live = row < rows;
         const float *lg = x + (size_t)(live ? row : 0) * C;
+        float v[4];
         float mx = -__builtin_huge_valf();
-        for (unsigned c = sub; c < C; c += L) mx = fmaxf(mx, lg[c]);
+        if (KEEP) {
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) {
+                const unsigned c = sub + k * L;
+                v[k] = c < C ? lg[c] : -__builtin_huge_valf();
+                mx = fmaxf(mx, v[k]);
+            }
+        } else {
+            for (unsigned c = sub; c < C; c += L) mx = fmaxf(mx, lg[c]);
+        }
         for (unsigned off = L >> 1; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
         float sum = 0.0f;
-        for (unsigned c = sub; c < C; c += L) sum += expf(lg[c] - mx);
+        if (KEEP) {
+#pragma unroll
+            for (unsigned k = 0; k < 4; ++k) {
+                v[k] = __builtin_amdgcn_exp2f((v[k] - mx) * LOG2E);        // (a slot past the row: exp2(-inf) = 0)
+                sum += v[k];
+            }
+        } else {
+            for (unsigned c = sub; c < C; c += L) sum += __builtin_amdgcn_exp2f((lg[c] - mx) * LOG2E);
+        }
         for (unsigned off = L >> 1; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-        const float lse = mx + logf(sum);
         if (!live) continue;
         const int64_t y = cls[row];
         float w = 0.0f;
@@ -154,13 +241,23 @@ __global__ __launch_bounds__(CLS_THREADS) void cross_entropy_kernel(const float 
             else w = weight ? weight[y] : 1.0f;
         }
         if (sub == 0 && w != 0.0f) {
-            num += w * (lse - lg[y]);
+            num += w * ((mx + __logf(sum)) - lg[y]);
             den += w;
         }
         if (grad) {
             float *gr = grad + (size_t)row * C;
-            for (unsigned c = sub; c < C; c += L)
-                gr[c] = w == 0.0f ? 0.0f : w * (expf(lg[c] - lse) - ((int64_t)c == y ? 1.0f : 0.0f));
+            const float scale = w == 0.0f ? 0.0f : w * __frcp_rn(sum);
+            if (KEEP) {
+#pragma unroll
+                for (unsigned k = 0; k < 4; ++k) {
+                    const unsigned c = sub + k * L;
+                    if (c < C) gr[c] = w == 0.0f ? 0.0f : v[k] * scale - ((int64_t)c == y ? w : 0.0f);
+                }
+            } else {
+                for (unsigned c = sub; c < C; c += L)
+                    gr[c] = w == 0.0f ? 0.0f
+                                      : __builtin_amdgcn_exp2f((lg[c] - mx) * LOG2E) * scale - ((int64_t)c == y ? w : 0.0f);
+            }
         }
     }
     if (bad) dm::raise_status(status, DM_ST_LABEL_RANGE);
@@ -217,15 +314,14 @@ extern "C" int dm_focal_loss_f32(const float *logits, const int64_t *target_cls,
     if (((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(grad_out)) & 15) != 0) return DM_E_INVALID_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned n = (unsigned)(rows * C);
-    const unsigned chunks = (n + 3) >> 2;
-    const int blocks = (int)std::max(1u, std::min((unsigned)CLS_MAX_BLOCKS, (chunks + CLS_THREADS - 1) / CLS_THREADS));
+    const unsigned quads = n >> 2;
+    const unsigned per_block = CLS_THREADS * FOCAL_QUADS;
+    const int blocks = (int)std::max(1u, std::min((unsigned)CLS_MAX_BLOCKS, (quads + per_block - 1) / per_block));
     const FocalParams fp{alpha, gamma, scale, ignore_index, use_ignore};
-    if (gamma == 2.0f)
-        hipLaunchKernelGGL(focal_loss_kernel<true>, dim3(blocks), dim3(CLS_THREADS), 0, st, logits, target_cls, n, (unsigned)C,
-                           fp, grad_out, partials, status);
-    else
-        hipLaunchKernelGGL(focal_loss_kernel<false>, dim3(blocks), dim3(CLS_THREADS), 0, st, logits, target_cls, n, (unsigned)C,
-                           fp, grad_out, partials, status);
+    auto kernel = gamma == 2.0f ? (C == 1 ? focal_loss_kernel<true, true> : focal_loss_kernel<true, false>)
+                                : (C == 1 ? focal_loss_kernel<false, true> : focal_loss_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(CLS_THREADS), 0, st, logits, target_cls, n, (unsigned)C, (unsigned)rows, fp,
+                       grad_out, partials, status);
     rc = dm::check_hip(hipGetLastError(), "focal_loss_kernel launch");
     if (rc != DM_OK) return rc;
     hipLaunchKernelGGL(cls_loss_finish_kernel<true>, dim3(1), dim3(CLS_THREADS), 0, st, partials, blocks, scale, loss_out);
@@ -244,8 +340,12 @@ extern "C" int dm_cross_entropy_f32(const float *logits, const int64_t *target_c
     const unsigned rows_per_block = CLS_THREADS / L;
     const unsigned want = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
     const int blocks = (int)std::max(1u, std::min((unsigned)CLS_MAX_BLOCKS, want));
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(blocks), dim3(CLS_THREADS), 0, st, logits, target_cls, weight, (unsigned)rows,
-                       (unsigned)C, L, ignore_index, grad_out, partials, status);
+    if ((unsigned)C <= 4 * L)
+        hipLaunchKernelGGL(cross_entropy_kernel<true>, dim3(blocks), dim3(CLS_THREADS), 0, st, logits, target_cls, weight,
+                           (unsigned)rows, (unsigned)C, L, ignore_index, grad_out, partials, status);
+    else
+        hipLaunchKernelGGL(cross_entropy_kernel<false>, dim3(blocks), dim3(CLS_THREADS), 0, st, logits, target_cls, weight,
+                           (unsigned)rows, (unsigned)C, L, ignore_index, grad_out, partials, status);
     rc = dm::check_hip(hipGetLastError(), "cross_entropy_kernel launch");
     if (rc != DM_OK) return rc;
     hipLaunchKernelGGL(cls_loss_finish_kernel<false>, dim3(1), dim3(CLS_THREADS), 0, st, partials, blocks, 1.0f, loss_out);

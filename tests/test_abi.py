@@ -150,3 +150,24 @@ def test_match_plan_reports_which_sets_need_the_cost_kernel():
     assert plan([600] * 12, 1024, 2, 28) == 12        # thousands of problems: the one-wavefront kernel reads cost blocks
     assert plan([300] * 6 + [20], 8, 2, 26) == 1      # T >= Q possible in the last set: the list-order kernel needs its blocks
     assert lib.dm_match_plan(None, 1, 1, 2, 1, None) == -1
+
+
+def test_classification_loss_argument_validation_without_gpu():
+    """The limits of dm_focal_loss_f32 / dm_cross_entropy_f32 are checked before any HIP call."""
+    import detr_amd
+    from detr_amd import _lib
+
+    lib = detr_amd.lib
+    ok_ptr = 4096                     # never dereferenced: every call below is refused first
+    assert lib.dm_focal_loss_f32(ok_ptr, ok_ptr, -1, 2, 0.25, 2.0, 1.0, 0, 0, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_INVALID_ARG
+    assert lib.dm_focal_loss_f32(ok_ptr, ok_ptr, 4, 0, 0.25, 2.0, 1.0, 0, 0, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_INVALID_ARG
+    assert lib.dm_focal_loss_f32(ok_ptr, ok_ptr, 4, 2, 0.25, 2.0, 1.0, 0, 0, None, None, ok_ptr, ok_ptr, None) == _lib.E_INVALID_ARG
+    assert lib.dm_focal_loss_f32(None, ok_ptr, 4, 2, 0.25, 2.0, 1.0, 0, 0, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_INVALID_ARG
+    # logits off a 16-byte boundary
+    assert lib.dm_focal_loss_f32(ok_ptr + 4, ok_ptr, 4, 2, 0.25, 2.0, 1.0, 0, 0, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_INVALID_ARG
+    # rows * C must stay below 2^31
+    assert lib.dm_focal_loss_f32(ok_ptr, ok_ptr, 1 << 30, 2, 0.25, 2.0, 1.0, 0, 0, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_UNSUPPORTED
+    assert lib.dm_cross_entropy_f32(ok_ptr, ok_ptr, None, 1 << 30, 2, -100, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_UNSUPPORTED
+    assert lib.dm_cross_entropy_f32(ok_ptr, None, None, 8, 3, -100, ok_ptr, None, ok_ptr, ok_ptr, None) == _lib.E_INVALID_ARG
+    assert lib.dm_cross_entropy_f32(ok_ptr, ok_ptr, None, 8, 3, -100, ok_ptr, None, None, ok_ptr, None) == _lib.E_INVALID_ARG
+    assert _lib.CLS_LOSS_PARTIALS == 4096

@@ -80,7 +80,7 @@ def test_focal_at_workload_sizes_against_stock_torch_ops(B, Q, C):
     c = x0.clone().requires_grad_(True)
     again = losses.focal_loss(c, cls, nb, 0.25, 2.0)
     (again * 1.7).backward()
-    assert float(again) == float(got) and torch.equal(c.grad, b.grad)
+    assert again.item() == got.item() and torch.equal(c.grad, b.grad)
 
 
 @pytest.mark.parametrize("B,Q,C", [(64, 600, 3), (8, 900, 92), (2, 31, 1204)])
@@ -175,7 +175,7 @@ def test_class_values_the_reference_refuses_are_reported():
         losses.check_cls_status()
     losses.check_cls_status()                       # reported once
     # the offending row counted as ignored
-    torch.testing.assert_close(bad * 17 / 18, good * 17 / 16)
+    torch.testing.assert_close(bad / 17, good / 16)
     cls[0, 0] = -7
     losses.cross_entropy(x, cls)
     with pytest.raises(RuntimeError):
