@@ -136,6 +136,9 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     ``CrossEntropy`` module (:185-213) -- gets the one-pass loss-and-gradient kernel of :mod:`detr_amd.losses` in front of
     its forward (`fuse_cls_criterion`; also for the denoising groups, which bring their own indices); a class value the
     reference's ``one_hot`` / ``cross_entropy`` would refuse is raised as RuntimeError when the criterion returns.
+    A Co-DETR criterion's ``calc_cls_loss_with_ignore`` (/root/reference/models/co_detr/loss.py:143-167) computes its
+    loss with the same kernel on the dense map with the ignored rows marked, in place of the boolean-mask gather (a
+    host synchronisation), the one-hot tensor and the elementwise chain.
     The wrappers are instance attributes holding local functions:
     `detach` the criterion before pickling the object itself (its ``state_dict`` is not affected).  Returns the
     matcher.  Calling it twice on one criterion is harmless."""
@@ -188,6 +191,39 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
 
             criterion.calc_cls_loss = calc_cls_loss
 
+    if fused_consumers and callable(getattr(criterion, "calc_cls_loss_with_ignore", None)) and hasattr(criterion, "n_cls"):
+        from . import losses
+
+        own_with_ignore = criterion.calc_cls_loss_with_ignore
+
+        def calc_cls_loss_with_ignore(outputs, targets, pos_indices, neg_indices):
+            """Co-DETR's classification loss for the Faster-RCNN style assigner
+            (/root/reference/models/co_detr/loss.py:143-167): the same dense class map -- -1 everywhere, the positives'
+            labels, `n_cls` on the negatives (:153-159) -- but the loss straight on it with the ignored rows skipped by
+            the kernel, instead of a boolean-mask gather of the foreground rows (a host synchronisation), a one-hot
+            tensor and the elementwise chain of `sigmoid_focal_loss` (:161-166, with that function's default alpha and
+            gamma, as the reference calls it)."""
+            logits = outputs["pred_logits"]
+            n_cls = criterion.n_cls
+            device = logits.device
+            if logits.dim() != 3 or logits.shape[-1] != n_cls \
+                    or not losses._takes(logits, torch.empty(0, dtype=torch.int64, device=device)):
+                return own_with_ignore(outputs, targets, pos_indices, neg_indices)
+            pos_b = [torch.full_like(src, b) for b, (src, _) in enumerate(pos_indices)]
+            neg_b = [torch.full_like(src, b) for b, src in enumerate(neg_indices)]
+            pos_s, neg_s = [src for src, _ in pos_indices], list(neg_indices)
+            n_pos = sum(int(s.shape[0]) for s in pos_s)
+            target_cls = torch.full(logits.shape[:2], -1, dtype=torch.int64, device=device)
+            if n_pos:
+                labels = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, pos_indices)])
+                target_cls[torch.cat(pos_b).to(device), torch.cat(pos_s).to(device)] = labels.to(device)
+            if sum(int(s.shape[0]) for s in neg_s):
+                target_cls[torch.cat(neg_b).to(device), torch.cat(neg_s).to(device)] = n_cls
+            cls_devices.add(device)
+            return losses.focal_loss(logits, target_cls, max(n_pos, 1), 0.25, 2.0, ignore_index=-1)
+
+        criterion.calc_cls_loss_with_ignore = calc_cls_loss_with_ignore
+
     def before(module, args, kwargs):
         outputs = args[0] if args else kwargs.get("outputs")
         targets = args[1] if len(args) > 1 else kwargs.get("targets")
@@ -226,7 +262,7 @@ def detach(criterion: torch.nn.Module) -> None:
         for h in hooks:
             h.remove()
         criterion._detr_amd_hooks = None
-        for name in ("calc_box_loss", "_get_src_permutation_idx", "calc_cls_loss"):
+        for name in ("calc_box_loss", "_get_src_permutation_idx", "calc_cls_loss", "calc_cls_loss_with_ignore"):
             if name in criterion.__dict__:
                 del criterion.__dict__[name]       # the class's own method shows again
         unfuse_cls_criterion(getattr(criterion, "cls_criterion", None))

@@ -121,10 +121,10 @@ def test_modules_take_the_references_call_convention():
     for channels_first in (None, True):
         mod = losses.FocalLoss(case.alpha, case.gamma, case.n_cls, channels_first=channels_first)
         loss = mod(x.transpose(1, 2), cls, case.num_boxes)
-        assert abs(float(loss) - case.loss) <= LOSS_RTOL * abs(case.loss)
+        assert abs(loss.item() - case.loss) <= LOSS_RTOL * abs(case.loss)
     for channels_first in (None, False):
         mod = losses.FocalLoss(case.alpha, case.gamma, case.n_cls, channels_first=channels_first)
-        assert abs(float(mod(x, cls, case.num_boxes)) - case.loss) <= LOSS_RTOL * abs(case.loss)
+        assert abs(mod(x, cls, case.num_boxes).item() - case.loss) <= LOSS_RTOL * abs(case.loss)
     x.grad = None
     losses.FocalLoss(case.alpha, case.gamma, case.n_cls)(x.transpose(1, 2), cls, case.num_boxes).backward()
     assert x.grad.shape == x.shape
@@ -134,8 +134,8 @@ def test_modules_take_the_references_call_convention():
     y = torch.from_numpy(ce.logits).cuda()
     ycls = torch.from_numpy(ce.target_cls).cuda()
     mod = losses.CrossEntropy(torch.from_numpy(ce.weight)).cuda()
-    assert abs(float(mod(y.transpose(1, 2), ycls, ce.num_boxes)) - ce.loss) <= LOSS_RTOL * abs(ce.loss)
-    assert abs(float(mod(y, ycls, ce.num_boxes)) - ce.loss) <= LOSS_RTOL * abs(ce.loss)
+    assert abs(mod(y.transpose(1, 2), ycls, ce.num_boxes).item() - ce.loss) <= LOSS_RTOL * abs(ce.loss)
+    assert abs(mod(y, ycls, ce.num_boxes).item() - ce.loss) <= LOSS_RTOL * abs(ce.loss)
 
 
 def test_what_the_kernel_does_not_take_goes_to_the_fallback():
@@ -199,4 +199,4 @@ def test_other_streams_and_unaligned_views():
     with torch.cuda.stream(side):
         loss = losses.focal_loss(view, cls, case.num_boxes, case.alpha, case.gamma)
     side.synchronize()
-    assert abs(float(loss) - case.loss) <= LOSS_RTOL * abs(case.loss)
+    assert abs(loss.item() - case.loss) <= LOSS_RTOL * abs(case.loss)

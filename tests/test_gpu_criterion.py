@@ -427,3 +427,68 @@ def test_fused_consumers_front_the_classification_criterion(kind):
     detach(crit)
     assert "forward" not in crit.cls_criterion.__dict__
     torch.testing.assert_close(crit(outputs, targets), want, rtol=1e-6, atol=1e-6)
+
+
+class IgnoreCriterion(torch.nn.Module):
+    """The part of Co-DETR's criterion that serves its Faster-RCNN style assigner, restated with stock torch ops
+    (/root/reference/models/co_detr/loss.py:143-167, 234-237)."""
+
+    def __init__(self, head, n_cls):
+        super().__init__()
+        self.matcher = types.SimpleNamespace(cls_loss="focal", cost_class=2.0, cost_bbox=5.0, cost_giou=2.0,
+                                             focal_alpha=0.25, focal_gamma=2.0)
+        self.aux_heads, self.n_cls = {"faster_rcnn": head}, n_cls
+
+    def calc_cls_loss_with_ignore(self, outputs, targets, pos_indices, neg_indices):
+        F = torch.nn.functional
+        logits = outputs["pred_logits"]
+        pidx = (torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(pos_indices)]), torch.cat([s for s, _ in pos_indices]))
+        nidx = (torch.cat([torch.full_like(s, i) for i, s in enumerate(neg_indices)]), torch.cat(list(neg_indices)))
+        num_boxes = max(len(pidx[0]), 1)
+        target_cls = torch.full(logits.shape[:2], -1, device=logits.device)
+        target_cls[pidx] = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, pos_indices)])
+        target_cls[nidx] = torch.cat([torch.full(i.shape, self.n_cls) for i in neg_indices]).to(logits.device)
+        fg = target_cls != -1
+        src, tgt = logits[fg], target_cls[fg]
+        onehot = F.one_hot(tgt, self.n_cls + 1)[..., :-1].float()
+        p = src.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(src, onehot, reduction="none")
+        p_t = p * onehot + (1 - p) * (1 - onehot)
+        loss = (0.25 * onehot + 0.75 * (1 - onehot)) * ce * (1 - p_t) ** 2.0
+        return loss[None].mean(1).sum() / num_boxes * src.shape[0]
+
+    def forward(self, outputs, targets):
+        total = 0.0
+        for output in outputs["aux"]["faster_rcnn"]:
+            pos, neg = self.aux_heads["faster_rcnn"](output, targets)
+            total = total + self.calc_cls_loss_with_ignore(output, targets, pos, neg)
+        return total
+
+
+@pytest.mark.gpu
+def test_fused_consumers_front_the_loss_with_ignored_predictions():
+    from detr_amd import aux_assign, synth
+    from detr_amd.criterion import attach, detach
+
+    wl, sets, targets = synth.make_workload("cfg3", device="cuda", batch=6)
+    sets = sets[:2]
+    for o in sets:
+        # predictions close to the targets, so that the assigner finds positives above its threshold
+        boxes = o["pred_boxes"].clone()
+        for b, t in enumerate(targets):
+            k = len(t["labels"])
+            boxes[b, :k] = t["boxes"] + 0.002
+        o["pred_boxes"] = boxes
+        o["pred_logits"].requires_grad_(True)
+    outputs = {"aux": {"faster_rcnn": sets}}
+    crit = IgnoreCriterion(aux_assign.FasterRCNN(), wl.n_label_classes)
+    want = crit(outputs, targets)
+    want_grads = torch.autograd.grad(want, [o["pred_logits"] for o in sets])
+    attach(crit, fused_consumers=True)
+    assert "calc_cls_loss_with_ignore" in crit.__dict__
+    got = crit(outputs, targets)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    for g, w in zip(torch.autograd.grad(got, [o["pred_logits"] for o in sets]), want_grads):
+        torch.testing.assert_close(g, w, rtol=5e-5, atol=2e-6 * float(w.abs().max()))
+    detach(crit)
+    assert "calc_cls_loss_with_ignore" not in crit.__dict__

@@ -328,3 +328,63 @@ def test_fused_consumers_inside_the_references_own_criteria(reference, fam, cls_
     assert "forward" not in criterion.cls_criterion.__dict__
     state = criterion.state_dict()
     assert all(".fallback" not in k for k in state)
+
+
+@pytest.mark.parametrize("aux_flag", [True, False])
+def test_fused_consumers_front_co_detrs_loss_with_ignore(reference, aux_flag, monkeypatch):
+    """Co-DETR with its auxiliary heads (the reference's own ATSS / Faster-RCNN assigners, left in place here because the
+    tensors are on the CPU): `calc_cls_loss_with_ignore` (co_detr/loss.py:143-167) is answered by the focal kernel on the
+    dense map with the ignored rows marked -- stood in for by stock torch ops that leave those rows out -- and the total
+    loss equals the unmodified criterion's."""
+    from detr_amd import losses as dm_losses
+    from detr_amd.criterion import attach, detach
+
+    matcher_mod, losses = reference
+    aux_mod = sys.modules["models.co_detr.auxiliary_head"]
+    gen = torch.Generator().manual_seed(900 + aux_flag)
+    outputs, targets, n_cls = _inputs("co_detr", "focal", gen)
+    # predictions close to the targets, so that the IoU thresholds of the Faster-RCNN assigner find positives
+    aux_sets = []
+    for _ in range(2):
+        o, _ = _set(3, 40, n_cls, gen)
+        for b, t in enumerate(targets):
+            k = len(t["labels"])
+            o["pred_boxes"][b, :k] = t["boxes"] + 0.002
+            o["pred_boxes"][b, k:2 * k] = t["boxes"] * torch.tensor([1.0, 1.0, 1.3, 1.3])
+        aux_sets.append(o)
+    outputs["aux"] = {"faster_rcnn": aux_sets, "atss": [_set(3, 40, n_cls, gen)[0]]}
+    heads = aux_mod.get_aux_heads(types.SimpleNamespace(aux_heads=["atss", "faster_rcnn"], atss_k=5))
+    criterion = losses["co_detr"].Criterion(matcher=matcher_mod.HungarianMatcher("focal", 2.0, 5.0, 2.0), n_cls=n_cls,
+                                            cls_loss="focal", aux_flag=aux_flag, aux_heads=heads)
+    want = criterion(outputs, targets)
+    pos, neg = heads["faster_rcnn"](aux_sets[-1], targets)
+    assert sum(len(s) for s, _ in pos) > 0 and sum(len(s) for s in neg) > 0         # the case is not vacuous
+
+    matcher = attach(criterion, fused_consumers=True, aux_heads=False)
+    assert "calc_cls_loss_with_ignore" in criterion.__dict__
+    matcher.match_flat = _cpu_flat_stand_in(matcher, [])
+    matcher.match_many = _oracle_match_many(matcher, [])          # (what the loop's calls reach once detached)
+    matcher.check_status = lambda: None
+    monkeypatch.setattr(dm_losses, "matched_box_losses", _torch_pair_losses)
+    ignore_calls = []
+
+    def focal_stand_in(x, cls, num_boxes, alpha, gamma, ignore_index=None):
+        onehot = torch.nn.functional.one_hot(cls.clamp(min=0), n_cls + 1)[..., :-1].float()
+        p = x.sigmoid()
+        ce = torch.nn.functional.binary_cross_entropy_with_logits(x, onehot, reduction="none")
+        p_t = p * onehot + (1 - p) * (1 - onehot)
+        loss = (alpha * onehot + (1 - alpha) * (1 - onehot)) * ce * (1 - p_t) ** gamma
+        if ignore_index is not None:
+            ignore_calls.append(int((cls == ignore_index).sum()))
+            loss = loss * (cls != ignore_index)[..., None]
+        return loss.sum() / num_boxes
+
+    monkeypatch.setattr(dm_losses, "_takes", lambda x, t: True)
+    monkeypatch.setattr(dm_losses, "focal_loss", focal_stand_in)
+    monkeypatch.setattr(dm_losses, "check_cls_status", lambda device=None: None)
+    got = criterion(outputs, targets)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    assert len(ignore_calls) == (2 if aux_flag else 1) and all(n > 0 for n in ignore_calls)
+    detach(criterion)
+    assert "calc_cls_loss_with_ignore" not in criterion.__dict__
+    torch.testing.assert_close(criterion(outputs, targets), want, rtol=1e-6, atol=1e-6)
