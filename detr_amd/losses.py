@@ -17,6 +17,11 @@ The classification loss on the dense class map (the criterion's `cls_criterion`,
 
 one pass over the logits per call (loss and gradient together) instead of a dozen elementwise torch kernels
 forward and as many backward.
+
+    set_losses(matcher, outputs_list, targets, n_cls, ...)    -> [(l1_loss, giou_loss, cls_loss)] per output set
+
+is the body of a criterion's loop over its Hungarian-matched output sets (loss.py:164-176) on top of all of the above:
+one matching launch for the step, nothing synchronises.
 """
 import ctypes
 from typing import List, Optional, Sequence, Tuple
@@ -324,3 +329,93 @@ class CrossEntropy(torch.nn.Module):
                 raise RuntimeError("detr_amd.losses.CrossEntropy: float32 GPU logits of [B, Q, C] or [B, C, Q] expected")
             return self.fallback(inputs, targets, num_boxes)
         return cross_entropy(x, targets, self.weight, self.ignore_index)
+
+
+def set_losses(matcher, outputs_list, targets, n_cls: int, cls_loss: str = "focal", focal_alpha: float = 0.25,
+               focal_gamma: float = 2.0, class_weight: Optional[torch.Tensor] = None
+               ) -> List[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+    """What the loop of the reference's `Criterion.forward` computes for its Hungarian-matched output sets
+    (/root/reference/models/detr/loss.py:164-176: matcher, `calc_box_loss`, `calc_cls_loss`), for all of
+    `outputs_list` (dicts with 'pred_logits' [B, Q, C] and 'pred_boxes' [B, Q, 4]) at once: `(l1_loss, giou_loss,
+    cls_loss)` per set, the same values and gradients, device scalars.  One matching launch for the step, one launch for
+    the pair losses of all sets, one for their class maps, one pass over each set's logits; no host synchronisation
+    (`matcher.check_status()` and `check_cls_status()` raise what the reference would have raised for bad inputs).
+    `cls_loss` 'ce': weighted cross entropy over n_cls + 1 classes with `class_weight` (the reference's ones with
+    `noobj_weight` last, :59-62); anything else: the focal loss over n_cls logits."""
+    outputs_list = list(outputs_list)
+    flats = matcher.match_flat(outputs_list, targets)
+    if not flats:
+        return []
+    box = matched_box_losses(outputs_list, flats)
+    maps = target_class_maps(flats, n_cls)
+    result = []
+    for o, f, (l1, giou), cls_map in zip(outputs_list, flats, box, maps):
+        logits = o["pred_logits"]
+        if cls_loss == "ce":
+            c = cross_entropy(logits, cls_map, class_weight)
+        else:
+            c = focal_loss(logits, cls_map, max(f.num_matched, 1), focal_alpha, focal_gamma)
+        result.append((l1, giou, c))
+    return result
+
+
+class _ClsLossOfSets(torch.autograd.Function):
+    """[S] classification losses of S output sets as ONE autograd node (the launches are still one pass per set)."""
+
+    @staticmethod
+    def forward(ctx, kind, maps, scales, alpha, gamma, weight, *logits):
+        S = len(logits)
+        checked = [_checked(x, m) for x, m in zip(logits, maps)]
+        device = checked[0][0].device
+        out = torch.empty(S, 2, dtype=torch.float32, device=device)
+        grads = [torch.empty_like(x) if ctx.needs_input_grad[6 + i] else None for i, (x, _) in enumerate(checked)]
+        if weight is not None:
+            weight = weight.detach().contiguous()
+        with torch.cuda.device(device):
+            partials, status, stream = _cls_buffers(device)
+            for i, ((x, cls), g) in enumerate(zip(checked, grads)):
+                g_ptr = g.data_ptr() if g is not None else None
+                if kind == "ce":
+                    rc = lib.dm_cross_entropy_f32(x.data_ptr(), cls.data_ptr(), weight.data_ptr() if weight is not None else None,
+                                                  cls.numel(), x.shape[-1], -100, out.data_ptr() + 8 * i, g_ptr,
+                                                  partials.data_ptr(), status.data_ptr(), stream)
+                else:
+                    rc = lib.dm_focal_loss_f32(x.data_ptr(), cls.data_ptr(), cls.numel(), x.shape[-1], alpha, gamma, scales[i],
+                                               0, 0, out.data_ptr() + 8 * i, g_ptr, partials.data_ptr(), status.data_ptr(),
+                                               stream)
+                _lib.check(rc, "dm_cross_entropy_f32" if kind == "ce" else "dm_focal_loss_f32")
+        ctx.kind, ctx.present = kind, [g is not None for g in grads]
+        ctx.save_for_backward(out, *[g for g in grads if g is not None])
+        return out[:, 0]
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        out, *bufs = ctx.saved_tensors
+        factors = grad_losses * out[:, 1] if ctx.kind == "ce" else grad_losses
+        picked = [f for f, present in zip(factors.unbind(0), ctx.present) if present]
+        scaled = iter(torch._foreach_mul(bufs, picked) if bufs else [])
+        return (None,) * 6 + tuple(next(scaled) if present else None for present in ctx.present)
+
+
+def set_loss_total(matcher, outputs_list, targets, n_cls: int, cls_loss: str = "focal", l1_weight: float = 1.0,
+                   giou_weight: float = 1.0, cls_weight: float = 1.0, focal_alpha: float = 0.25, focal_gamma: float = 2.0,
+                   class_weight: Optional[torch.Tensor] = None, reduction: str = "mean") -> torch.Tensor:
+    """`l1_weight * l1 + giou_weight * giou + cls_weight * cls` over the Hungarian-matched output sets of ONE output group
+    as one scalar -- with reduction='mean' what the reference's `calc_total_loss` makes of the group's per-layer losses
+    (/root/reference/models/detr/loss.py:135-158: the mean of each kind over the layers, weighted and summed) -- with
+    three autograd nodes for the whole group instead of some twenty per set: the values of `set_losses`, and a step that
+    is no longer bound by the host's walk through tiny tensor operations."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError("reduction must be 'mean' or 'sum'")
+    outputs_list = list(outputs_list)
+    flats = matcher.match_flat(outputs_list, targets)
+    if not flats:
+        raise ValueError("no output sets")
+    S = len(flats)
+    share = 1.0 / S if reduction == "mean" else 1.0
+    box = matched_box_loss_total(outputs_list, flats, l1_weight, giou_weight, reduction=reduction)
+    maps = target_class_maps(flats, n_cls)
+    scales = [1.0 / float(max(f.num_matched, 1)) for f in flats]
+    cls = _ClsLossOfSets.apply("ce" if cls_loss == "ce" else "focal", maps, scales, float(focal_alpha), float(focal_gamma),
+                               class_weight, *[o["pred_logits"] for o in outputs_list])
+    return box + cls.sum() * (share * cls_weight)

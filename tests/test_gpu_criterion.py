@@ -492,3 +492,56 @@ def test_fused_consumers_front_the_loss_with_ignored_predictions():
         torch.testing.assert_close(g, w, rtol=5e-5, atol=2e-6 * float(w.abs().max()))
     detach(crit)
     assert "calc_cls_loss_with_ignore" not in crit.__dict__
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["focal", "ce"])
+def test_set_losses_and_their_total_equal_the_loop_of_a_reference_style_criterion(kind):
+    """detr_amd.losses.set_losses / set_loss_total: the body of Criterion.forward's loop (loss.py:164-176) and the group's
+    weighted total (:135-158) -- the same per-set values, the same total and the same gradients w.r.t. logits and boxes as
+    a criterion in the reference's style computes with stock torch ops."""
+    import detr_amd
+    from detr_amd import losses, synth
+
+    wl, sets, targets = synth.make_workload("cfg1" if kind == "ce" else "cfg3", device="cuda", batch=5)
+    sets = sets[:3]
+    n_cls = wl.n_label_classes
+    for o in sets:
+        o["pred_boxes"].requires_grad_(True)
+        o["pred_logits"].requires_grad_(True)
+    leaves = [o["pred_logits"] for o in sets] + [o["pred_boxes"] for o in sets]
+    weight = torch.ones(n_cls + 1)
+    weight[-1] = 0.1
+    weight = weight.cuda()
+    cls_criterion = FocalLoss(0.25, 2.0, n_cls) if kind == "focal" else CrossEntropy(weight).cuda()
+    matcher = detr_amd.HungarianMatcher(**wl.matcher_kwargs)
+    plain = ClsCriterion(matcher, cls_criterion, n_cls)
+    want_sets = []
+    for o in sets:                                     # the loop of Criterion.forward
+        plain.class_maps = []
+        indices = matcher(o, targets)
+        l1, giou = plain.calc_box_loss(o, targets, indices)
+        want_sets.append((l1, giou, plain.calc_cls_loss(o, targets, indices)))
+    # calc_total_loss: the mean of each kind over the layers, weighted and summed
+    want = sum(w * sum(v[k] for v in want_sets) / len(want_sets) for k, w in enumerate((5.0, 2.0, 2.0)))
+    want_grads = torch.autograd.grad(want, leaves)
+
+    got_sets = losses.set_losses(matcher, sets, targets, n_cls, kind, class_weight=weight)
+    for g3, w3 in zip(got_sets, want_sets):
+        for g, w in zip(g3, w3):
+            torch.testing.assert_close(g, w, rtol=1e-5, atol=1e-6)
+    got = losses.set_loss_total(matcher, sets, targets, n_cls, kind, 5.0, 2.0, 2.0, class_weight=weight)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    for g, w in zip(torch.autograd.grad(got, leaves), want_grads):
+        torch.testing.assert_close(g, w, rtol=5e-5, atol=2e-6 * float(w.abs().max()))
+    total_sum = losses.set_loss_total(matcher, sets, targets, n_cls, kind, 5.0, 2.0, 2.0, class_weight=weight, reduction="sum")
+    torch.testing.assert_close(total_sum, want * len(sets), rtol=1e-5, atol=1e-5)
+    matcher.check_status()
+    losses.check_cls_status()
+    # logits that need no gradient: only the boxes get one
+    frozen = [dict(o, pred_logits=o["pred_logits"].detach()) for o in sets]
+    part = losses.set_loss_total(matcher, frozen, targets, n_cls, kind, 5.0, 2.0, 2.0, class_weight=weight)
+    for g, w in zip(torch.autograd.grad(part, [o["pred_boxes"] for o in sets]), want_grads[3:]):
+        torch.testing.assert_close(g, w, rtol=5e-5, atol=2e-6 * float(w.abs().max()))
+    with pytest.raises(ValueError):
+        losses.set_loss_total(matcher, sets, targets, n_cls, kind, reduction="max")

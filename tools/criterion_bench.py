@@ -13,6 +13,8 @@ with stock torch ops).
   attach, fused consumers + fused_consumers=True: calc_box_loss and _get_src_permutation_idx answered from the flat buffer,
                          calc_cls_loss on one pseudo-image, the classification criterion fronted by the one-pass kernel
                          (the line before it: the same with the criterion's own FocalLoss / CrossEntropy left in place)
+  forward on set_losses  the loop of Criterion.forward replaced by detr_amd.losses.set_losses (an edited criterion)
+  forward on set_loss_total  ... by detr_amd.losses.set_loss_total: the group's weighted total as one scalar
 """
 import os
 import sys
@@ -104,6 +106,31 @@ class Criterion(torch.nn.Module):
         return total / len(outputs["model"])
 
 
+class RewrittenCriterion(torch.nn.Module):
+    """The same total with the loop replaced by detr_amd.losses.set_losses (what a maintainer who edits
+    Criterion.forward gets)."""
+
+    def __init__(self, matcher, n_cls, cls_loss):
+        super().__init__()
+        self.matcher, self.n_cls, self.cls_loss, self.one_scalar = matcher, n_cls, cls_loss, False
+        weight = torch.ones(n_cls + 1)
+        weight[-1] = 0.1
+        self.register_buffer("weight", weight)
+
+    def forward(self, outputs, targets):
+        from detr_amd import losses
+
+        if self.one_scalar:
+            return losses.set_loss_total(self.matcher, outputs["model"], targets, self.n_cls, self.cls_loss, 5.0, 2.0, 2.0,
+                                         class_weight=self.weight)
+        per_set = losses.set_losses(self.matcher, outputs["model"], targets, self.n_cls, self.cls_loss,
+                                    class_weight=self.weight)
+        total = 0.0
+        for l1, giou, cls in per_set:
+            total = total + 5.0 * l1 + 2.0 * giou + 2.0 * cls
+        return total / len(per_set)
+
+
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 wl, sets, targets = synth.make_workload(name, device="cuda")
 for o in sets:
@@ -140,3 +167,8 @@ print("  fused, own class loss    %8.2f   %.6f" % timeit(crit))
 detach(crit)
 attach(crit, fused_consumers=True)
 print("  attach, fused consumers  %8.2f   %.6f" % timeit(crit))
+detach(crit)
+new = RewrittenCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss).cuda()
+print("  forward on set_losses    %8.2f   %.6f" % timeit(new))
+new.one_scalar = True
+print("  forward on set_loss_total %7.2f   %.6f" % timeit(new))
