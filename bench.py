@@ -205,6 +205,42 @@ def flat_path(matcher, sets, targets, device, steps):
             "what": "match_flat on pre-packed targets: device-resident flat indices, one sync after all steps"}
 
 
+def criterion_step(matcher, wl, sets, fresh, device, steps):
+    """Not the headline: the matcher together with what consumes its indices -- matching, the L1 / GIoU losses of the
+    matched pairs, the class maps and the classification loss of every output set, forward and backward, as one
+    weighted scalar (detr_amd.losses.set_loss_total: the loop of /root/reference/models/detr/loss.py:164-176 and
+    calc_total_loss :135-158 for one output group).  New target tensors every step; one synchronisation at the end."""
+    from detr_amd import losses
+
+    leaves = [dict(o, pred_logits=o["pred_logits"].detach().clone().requires_grad_(True),
+                   pred_boxes=o["pred_boxes"].detach().clone().requires_grad_(True)) for o in sets]
+    weight = torch.ones(wl.n_label_classes + 1, device=device)
+    weight[-1] = 0.1
+
+    def step(turn):
+        total = losses.set_loss_total(matcher, leaves, fresh[turn & 3], wl.n_label_classes, wl.cls_loss, 5.0, 2.0, 2.0,
+                                      class_weight=weight)
+        total.backward()
+        for o in leaves:
+            o["pred_logits"].grad = o["pred_boxes"].grad = None
+        return total
+
+    steps = max(10, min(steps, 100))
+    for k in range(5):
+        step(k)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        total = step(k)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    matcher.check_status()
+    losses.check_cls_status(device)
+    return {"ms_per_step": 1e3 * elapsed / steps, "steps": steps, "loss": float(total.detach()),
+            "what": "detr_amd.losses.set_loss_total forward + backward: matching, pair losses, class maps and the "
+                    "classification loss of all output sets as one scalar; no synchronisation inside the loop"}
+
+
 def per_layer_calls(matcher, sets, fresh, device, steps, prefetch=False):
     """The step as the reference's criteria drive it when only the import is swapped: one
     `matcher(output, targets)` call per output set, in a Python loop, every call handing its CPU tuples back
@@ -547,6 +583,7 @@ def main():
             record["flat_path"] = flat_path(matcher, sets, targets, device, args.steps)
             record["per_layer_calls"] = per_layer_calls(matcher, sets, fresh, device, args.steps)
             record["per_layer_calls_prefetched"] = per_layer_calls(matcher, sets, fresh, device, args.steps, prefetch=True)
+            record["criterion_step"] = criterion_step(matcher, wl, sets, fresh, device, args.steps)
         if stress is not None:
             record["roofline_stress"] = stress
         if world == 1 and not args.no_cpu_baseline:

@@ -27,6 +27,10 @@ def test_bench_json_line():
         assert key in roof, key
     assert roof["bound"] == "hbm" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0 < rec["roofline_stress"]["frac"] < 1.0
+    # the extras beside the headline: other contracts of the same path, and the matcher together with its consumers
+    for key in ("flat_path", "per_layer_calls", "per_layer_calls_prefetched", "criterion_step"):
+        assert rec[key]["ms_per_step"] > 0, key
+    assert rec["criterion_step"]["loss"] > 0
 
 
 def _bench(*flags):
