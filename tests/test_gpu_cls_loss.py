@@ -83,7 +83,10 @@ def test_focal_at_workload_sizes_against_stock_torch_ops(B, Q, C):
     assert again.item() == got.item() and torch.equal(c.grad, b.grad)
 
 
-@pytest.mark.parametrize("B,Q,C", [(64, 600, 3), (8, 900, 92), (2, 31, 1204)])
+# (class counts that take each kernel: a few logits per thread, 2^k lanes per row, the 16-byte variant for C = 0 mod 4 with
+# one lane and with a wavefront per row, the cached three-pass walk beyond 1024 classes)
+@pytest.mark.parametrize("B,Q,C", [(64, 600, 3), (8, 900, 92), (2, 31, 1204), (5, 33, 4), (3, 50, 512), (2, 31, 1024),
+                                   (3, 41, 90), (2, 37, 257)])
 def test_cross_entropy_at_workload_sizes_against_stock_torch_ops(B, Q, C):
     from detr_amd import losses
 
@@ -200,3 +203,35 @@ def test_other_streams_and_unaligned_views():
         loss = losses.focal_loss(view, cls, case.num_boxes, case.alpha, case.gamma)
     side.synchronize()
     assert abs(loss.item() - case.loss) <= LOSS_RTOL * abs(case.loss)
+
+
+def test_cross_entropy_off_a_16_byte_boundary():
+    """Logits that do not start on a 16-byte boundary reach the C entry point as they are only when the Python layer lets
+    them: it copies.  Called through the C ABI directly, dm_cross_entropy_f32 takes them with its 4-byte kernels."""
+    import ctypes
+
+    from detr_amd import _lib, losses
+    from detr_amd._lib import lib
+
+    case = golden_io.ClsLossCase("syn_ce_c92")
+    n = case.logits.size
+    base = torch.zeros(n + 1, device="cuda")
+    view = base[1:].view(case.logits.shape)
+    view.copy_(torch.from_numpy(case.logits))
+    assert view.data_ptr() % 16 == 4
+    cls = torch.from_numpy(case.target_cls).cuda()
+    w = torch.from_numpy(case.weight).cuda()
+    out = torch.zeros(2, device="cuda")
+    grad = torch.zeros(n + 1, device="cuda")[1:]
+    partials = torch.empty(_lib.CLS_LOSS_PARTIALS, dtype=torch.float64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rc = lib.dm_cross_entropy_f32(view.data_ptr(), cls.data_ptr(), w.data_ptr(), cls.numel(), 92, -100, out.data_ptr(),
+                                  grad.data_ptr(), partials.data_ptr(), status.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert abs(out[0].item() - case.loss) <= LOSS_RTOL * abs(case.loss) and int(status.item()) == 0
+    got = (grad * out[1]).view(case.logits.shape).cpu().numpy()
+    np.testing.assert_allclose(got, case.grad, rtol=GRAD_RTOL, atol=GRAD_FLOOR * float(np.abs(case.grad).max()))
+    # and through the Python layer (which hands the kernel an aligned copy)
+    assert abs(losses.cross_entropy(view, cls, w).item() - case.loss) <= LOSS_RTOL * abs(case.loss)

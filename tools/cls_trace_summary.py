@@ -13,7 +13,7 @@ path, B, Q, C = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
 seq = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
 focal = [d for n, d in seq if "focal_loss_kernel" in n]
-ce = [d for n, d in seq if "cross_entropy_kernel" in n]
+ce = [d for n, d in seq if "cross_entropy_" in n]
 fin = [d for n, d in seq if "cls_loss_finish_kernel" in n]
 mb_in = (4 * B * Q * C + 8 * B * Q) / 1e6
 mb_both = (8 * B * Q * C + 8 * B * Q) / 1e6
