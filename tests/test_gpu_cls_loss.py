@@ -235,3 +235,44 @@ def test_cross_entropy_off_a_16_byte_boundary():
     np.testing.assert_allclose(got, case.grad, rtol=GRAD_RTOL, atol=GRAD_FLOOR * float(np.abs(case.grad).max()))
     # and through the Python layer (which hands the kernel an aligned copy)
     assert abs(losses.cross_entropy(view, cls, w).item() - case.loss) <= LOSS_RTOL * abs(case.loss)
+
+
+def test_random_shapes_against_the_oracle():
+    """Seeded sweep over row counts, class counts (1 .. 130: every position of a quad of four logits relative to the
+    row boundaries, tails of one to three logits, the one-class and the 16-byte cross-entropy kernels), gamma, alpha,
+    ignored rows and class weights: loss and gradient against the CPU restatement."""
+    from detr_amd import losses
+    from oracle import cls_loss as oracle_cls
+
+    rng = np.random.default_rng(20240607)
+    for trial in range(80):
+        B, Q = int(rng.integers(1, 5)), int(rng.integers(1, 70))
+        C = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 31, 64, 91, 92, 130]))
+        x = (rng.standard_normal((B, Q, C)) * 3).astype(np.float32)
+        if trial % 2 == 0:
+            gamma = float(rng.choice([2.0, 2.0, 0.0, 1.0, 1.5, 3.0]))
+            alpha = float(rng.choice([0.25, 0.6, -1.0]))
+            cls = rng.integers(0, C + 1, (B, Q))
+            ignore = None
+            if trial % 4 == 0:
+                ignore = -1
+                cls[rng.random((B, Q)) < 0.3] = -1
+            nb = int(rng.integers(1, 20))
+            want, want_grad = oracle_cls.focal_loss(x, cls, nb, alpha, gamma, ignore_index=ignore)
+            xt = torch.from_numpy(x).cuda().requires_grad_(True)
+            got = losses.focal_loss(xt, torch.from_numpy(cls).cuda(), nb, alpha, gamma, ignore_index=ignore)
+        else:
+            cls = rng.integers(0, C, (B, Q))
+            cls[rng.random((B, Q)) < 0.2] = -100
+            if (cls == -100).all():
+                cls[0, 0] = 0
+            w = (rng.random(C) + 0.1).astype(np.float32) if trial % 4 == 1 else None
+            want, want_grad = oracle_cls.cross_entropy(x, cls, w)
+            xt = torch.from_numpy(x).cuda().requires_grad_(True)
+            got = losses.cross_entropy(xt, torch.from_numpy(cls).cuda(), None if w is None else torch.from_numpy(w).cuda())
+        got.backward()
+        what = (trial, B, Q, C)
+        assert abs(got.item() - float(want)) <= LOSS_RTOL * abs(float(want)) + 1e-7, what
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), want_grad, rtol=GRAD_RTOL,
+                                   atol=GRAD_FLOOR * float(np.abs(want_grad).max()) + 1e-12, err_msg=str(what))
+    losses.check_cls_status()
