@@ -47,7 +47,7 @@ EXPORTS = ["dm_pack_targets", "dm_abi_version", "dm_strerror", "dm_last_hip_erro
            "dm_cost_f32", "dm_lap_f32", "dm_match_f32", "dm_lap_flat_f32", "dm_match_flat_f32", "dm_match_fused_f32", "dm_match_targets_f32", "dm_match_noalloc_f32", "dm_noalloc_scratch",
            "dm_profile_enable", "dm_profile_read", "dm_match_plan",
            "dm_debug_set_knob",
-           "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_target_classes_i64",
+           "dm_pair_loss_f32", "dm_pair_loss_backward_f32", "dm_pair_list_loss_f32", "dm_pair_list_backward_f32", "dm_target_classes_i64",
            "dm_focal_loss_f32", "dm_cross_entropy_f32",
            "dm_atss_f32", "dm_frcnn_f32", "dm_frcnn_dense_i64"]
 
@@ -95,6 +95,10 @@ def _load():
     lib.dm_pair_loss_f32.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, vp, vp, vp]
     lib.dm_pair_loss_backward_f32.restype = ctypes.c_int
     lib.dm_pair_loss_backward_f32.argtypes = [isetp, i32, i32, i32, vp, i64p, i64p, vp, vp, vp]
+    lib.dm_pair_list_loss_f32.restype = ctypes.c_int
+    lib.dm_pair_list_loss_f32.argtypes = [vp, i32, i32, i32, vp, i32, i64p, i64p, i64p, ctypes.c_int64, vp, vp, vp, vp, vp]
+    lib.dm_pair_list_backward_f32.restype = ctypes.c_int
+    lib.dm_pair_list_backward_f32.argtypes = [vp, vp, i64p, i64p, ctypes.c_int64, i32, i32, vp, vp]
     lib.dm_target_classes_i64.restype = ctypes.c_int
     lib.dm_target_classes_i64.argtypes = [isetp, i32, i32, i32, vp, vp, i64p, i64p, ctypes.c_int64, vp]
     lib.dm_focal_loss_f32.restype = ctypes.c_int

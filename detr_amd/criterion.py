@@ -16,6 +16,7 @@ waiting.  The criterion's code stays as it is; a set the hook did not foresee is
 """
 from typing import Iterable, Sequence
 
+import numpy as np
 import torch
 
 from .matcher import HungarianMatcher
@@ -111,6 +112,53 @@ def unfuse_cls_criterion(own) -> None:
         del own.__dict__["forward"]
 
 
+def flat_of_foreign_indices(matcher: HungarianMatcher, outputs, targets, indices):
+    """A `FlatMatches` for index tuples that did NOT come from the matcher -- the denoising groups of DN-DETR / DINO /
+    Co-DETR bring their own `(query indices, target indices)` per image together with their own targets
+    (/root/reference/models/dino_detr/loss.py:170-172, built at dino_func.py:117-129) -- so that the consumers of
+    :mod:`detr_amd.losses` can work on them like on a served result: image, query and packed-target position of every
+    pair as three device tensors, the targets packed once.  Built once per `indices` object and kept until the matcher's
+    prefetched results are dropped (the same indices serve every decoder layer of a step).  None when these are not
+    per-image pairs of int64 index tensors for GPU predictions -- the caller then uses its own code."""
+    from . import losses, matcher as matcher_module
+
+    FlatMatches, PackedTargets = matcher_module.FlatMatches, matcher_module.PackedTargets
+    flat = matcher.served_flat_of(indices)
+    if flat is not None:
+        return flat if getattr(flat, "foreign_targets", None) is targets else None
+    pred = outputs.get("pred_boxes") if isinstance(outputs, dict) else None
+    if pred is None or not losses._takes_boxes(pred) or not isinstance(indices, (list, tuple)):
+        return None
+    B = int(pred.shape[0])
+    if len(indices) != B or not isinstance(targets, (list, tuple)) or len(targets) != B:
+        return None
+    try:
+        srcs, tgts = [s for s, _ in indices], [t for _, t in indices]
+        for s_, t_ in zip(srcs, tgts):
+            if s_.dtype != torch.int64 or t_.dtype != torch.int64 or s_.dim() != 1 or s_.shape != t_.shape \
+                    or s_.device != srcs[0].device or t_.device != srcs[0].device:
+                return None
+        packed = PackedTargets(targets, pred.device)
+    except (TypeError, ValueError, RuntimeError, KeyError, AttributeError):
+        return None
+    lens = np.asarray([int(s_.shape[0]) for s_ in srcs], dtype=np.int64)
+    n = int(lens.sum())
+    if n == 0:
+        return None
+    # (numpy: torch's CPU repeat_interleave wakes its thread pool, a millisecond for 64 numbers)
+    image = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int64), lens))
+    first = torch.from_numpy(np.repeat(np.asarray(packed.offsets_list[:-1], dtype=np.int64), lens))
+    if srcs[0].device.type == "cpu":            # (the reference builds them with torch.arange on the host)
+        trio = torch.stack([image, torch.cat(srcs), torch.cat(tgts) + first]).to(pred.device)
+        image, query, slot = trio[0], trio[1], trio[2]
+    else:
+        image, query, slot = image.to(pred.device), torch.cat(srcs), torch.cat(tgts) + first.to(pred.device)
+    flat = FlatMatches(image, query, None, slot, packed, int(pred.shape[1]))
+    flat.foreign_targets = targets
+    matcher.register_flat_view(indices, flat)
+    return flat
+
+
 def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_heads: bool = True,
            device_indices: bool = False, fused_consumers: bool = False) -> HungarianMatcher:
     """Make `criterion` (an instance of one of the reference's Criterion classes, or anything that keeps its
@@ -126,7 +174,11 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
     (/root/reference/models/detr/loss.py:97-114) by the fused pair-loss kernel of :mod:`detr_amd.losses` (same two
     values, same gradient, O(pairs) instead of the [N, N] GIoU matrix and 2B gathers) and
     ``_get_src_permutation_idx(indices)`` (:71-75) by two ready tensors instead of B ``full_like`` calls and two
-    concatenations; indices from elsewhere (the denoising groups') go to the criterion's own methods.
+    concatenations.  Indices from elsewhere -- the denoising groups bring their own, several groups of queries per
+    target, with their own targets -- are flattened once per step (`flat_of_foreign_indices`) and take the same
+    routes: the box loss by the pair-list kernel (the reference's [N, N] matrix has N = groups x targets of the whole
+    batch there), the class loss on the pseudo-image; anything that is not a list of per-image int64 index pairs for
+    GPU predictions goes to the criterion's own methods.
     ``calc_cls_loss(outputs, targets, indices, ...)`` (:116-133) keeps the criterion's own body -- its class map, its
     classification loss, its accuracy log -- but is handed the batch as ONE pseudo-image: the packed labels as the
     only target and one (src, flat target index) pair as the only result, so that its per-image label gathers
@@ -161,10 +213,20 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
 
         def calc_box_loss(outputs, targets, indices):
             m = criterion.matcher
-            flat = m.served_flat(outputs, indices) if isinstance(m, HungarianMatcher) else None
+            if not isinstance(m, HungarianMatcher):
+                return own_box_loss(outputs, targets, indices)
+            flat = m.served_flat(outputs, indices)
+            if flat is not None:
+                return losses.matched_box_losses([outputs], [flat])[0]
+            # indices from elsewhere (the denoising groups'): the same two values from the list of pairs, O(pairs)
+            pred = outputs.get("pred_boxes") if isinstance(outputs, dict) else None
+            flat = flat_of_foreign_indices(m, outputs, targets, indices) if pred is not None and losses._takes_boxes(pred) else None
             if flat is None:
                 return own_box_loss(outputs, targets, indices)
-            return losses.matched_box_losses([outputs], [flat])[0]
+            cls_devices.add(pred.device)
+            sums = losses.pair_list_box_loss_sums(pred, flat.packed.boxes, flat.batch_idx, flat.src_idx, flat.tgt_flat)
+            n = float(max(flat.num_matched, 1))
+            return sums[0] / n, sums[1] / n
 
         criterion.calc_box_loss = calc_box_loss       # (an instance attribute in front of the class's method)
     if fused_consumers and callable(getattr(criterion, "_get_src_permutation_idx", None)):
@@ -182,6 +244,8 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
             def calc_cls_loss(outputs, targets, indices, *args, **kwargs):
                 m = criterion.matcher
                 flat = m.served_flat(outputs, indices) if isinstance(m, HungarianMatcher) else None
+                if flat is None and isinstance(m, HungarianMatcher):
+                    flat = flat_of_foreign_indices(m, outputs, targets, indices)
                 if flat is None:
                     return own_cls_loss(outputs, targets, indices, *args, **kwargs)
                 one_pair = [(flat.src_idx, flat.tgt_flat)]

@@ -184,6 +184,100 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const DmIndexSetArray
     }
 }
 
+// The same two sums for an explicit list of (image, query, packed target) pairs -- indices that did not come from the
+// matcher: the denoising groups of DN-DETR / DINO / Co-DETR bring theirs along (several groups of queries per target),
+// an auxiliary assigner may pair one prediction with several targets.  Any number of workgroups; each leaves its two
+// partial sums, which pair_list_finish_kernel adds in index order.
+constexpr int PAIR_LIST_THREADS = 256;
+constexpr int PAIR_LIST_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(PAIR_LIST_THREADS) void pair_list_loss_kernel(const float *__restrict__ pred_boxes, const size_t image_rows,
+                                                                          const int B, const int Q, const int M,
+                                                                          const float *__restrict__ tgt_boxes,
+                                                                          const int64_t *__restrict__ pair_b,
+                                                                          const int64_t *__restrict__ pair_q,
+                                                                          const int64_t *__restrict__ pair_t, const int64_t N,
+                                                                          float *__restrict__ pair_grad,
+                                                                          double *__restrict__ partials, int32_t *__restrict__ status)
+{
+    __shared__ double red[2][PAIR_LIST_THREADS / 64];
+    const float4 *pred = reinterpret_cast<const float4 *>(pred_boxes);
+    const float4 *gts = reinterpret_cast<const float4 *>(tgt_boxes);
+    float l1 = 0.0f, gl = 0.0f;
+    bool bad = false;
+    for (int64_t k = (int64_t)blockIdx.x * PAIR_LIST_THREADS + threadIdx.x; k < N; k += (int64_t)gridDim.x * PAIR_LIST_THREADS) {
+        const int64_t b = pair_b[k], q = pair_q[k], t = pair_t[k];
+        float out[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (b < 0 || b >= B || q < 0 || q >= Q || t < 0 || t >= M) {
+            bad = true;                     // (the reference's gathers raise IndexError; the pair contributes nothing)
+        } else {
+            const float4 pb = pred[(size_t)b * image_rows + (size_t)q];
+            const float4 gb = gts[t];
+            const float d0 = pb.x - gb.x, d1 = pb.y - gb.y, d2 = pb.z - gb.z, d3 = pb.w - gb.w;
+            l1 += ((fabsf(d0) + fabsf(d1)) + fabsf(d2)) + fabsf(d3);
+            out[0] = sign_of(d0); out[1] = sign_of(d1); out[2] = sign_of(d2); out[3] = sign_of(d3);
+            gl += pair_giou_loss(pb, gb, out + 4);
+        }
+        if (pair_grad) {
+            float4 *dst = reinterpret_cast<float4 *>(pair_grad + (size_t)k * 8);
+            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+        }
+    }
+    if (bad) dm::raise_status(status, DM_ST_LABEL_RANGE);
+    double a = (double)l1, c = (double)gl;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off);
+        c += __shfl_xor(c, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = a; red[1][wave] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0.0, sc = 0.0;
+        for (int w = 0; w < PAIR_LIST_THREADS / 64; ++w) { sa += red[0][w]; sc += red[1][w]; }
+        partials[2 * blockIdx.x] = sa;
+        partials[2 * blockIdx.x + 1] = sc;
+    }
+}
+
+__global__ __launch_bounds__(64) void pair_list_finish_kernel(const double *__restrict__ partials, const int blocks,
+                                                               float *__restrict__ sums)
+{
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += 64) { a += partials[2 * i]; c += partials[2 * i + 1]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off);
+        c += __shfl_xor(c, off);
+    }
+    if (threadIdx.x == 0) { sums[0] = (float)a; sums[1] = (float)c; }
+}
+
+// Backward of the pair list: grad_boxes[b][q] += w_l1 * d l1 + w_giou * d (1 - giou) for every pair.  A query may occur in
+// several pairs, so the four components are added with hardware float atomics (the order of the additions, and with
+// it the last bit of such a query's gradient, is then not fixed; a query in one pair gets exactly its value).
+__global__ __launch_bounds__(PAIR_LIST_THREADS) void pair_list_backward_kernel(const float *__restrict__ pair_grad,
+                                                                              const float *__restrict__ grad_sums,
+                                                                              const int64_t *__restrict__ pair_b,
+                                                                              const int64_t *__restrict__ pair_q, const int64_t N,
+                                                                              const int B, const int Q, float *__restrict__ grad_boxes)
+{
+    const float w_l1 = grad_sums[0], w_giou = grad_sums[1];
+    for (int64_t k = (int64_t)blockIdx.x * PAIR_LIST_THREADS + threadIdx.x; k < N; k += (int64_t)gridDim.x * PAIR_LIST_THREADS) {
+        const int64_t b = pair_b[k], q = pair_q[k];
+        if (b < 0 || b >= B || q < 0 || q >= Q) continue;
+        const float4 *pg = reinterpret_cast<const float4 *>(pair_grad + (size_t)k * 8);
+        const float4 a = pg[0], c = pg[1];
+        float *dst = grad_boxes + ((size_t)b * Q + (size_t)q) * 4;
+        unsafeAtomicAdd(dst + 0, w_l1 * a.x + w_giou * c.x);
+        unsafeAtomicAdd(dst + 1, w_l1 * a.y + w_giou * c.y);
+        unsafeAtomicAdd(dst + 2, w_l1 * a.z + w_giou * c.z);
+        unsafeAtomicAdd(dst + 3, w_l1 * a.w + w_giou * c.w);
+    }
+}
+
 int check_sets(const DmIndexSet *sets, int S, int B, int M)
 {
     if (S < 0 || B < 0 || M < 0) return DM_E_INVALID_ARG;
@@ -276,4 +370,41 @@ extern "C" int dm_target_classes_i64(const DmIndexSet *sets, int S, int B, int M
     if (M > 0 && !tgt_labels) return DM_E_INVALID_ARG;
     return launch_scatter<true>(sets, S, B, M, tgt_off, src, tgt, nullptr, nullptr, tgt_labels, no_object,
                                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dm_pair_list_loss_f32(const float *pred_boxes, int boxes_stride, int B, int Q, const float *tgt_boxes, int M,
+                                     const int64_t *pair_b, const int64_t *pair_q, const int64_t *pair_t, int64_t N,
+                                     float *sums, float *pair_grad, double *partials, int32_t *status, void *stream)
+{
+    if (B < 0 || Q < 1 || M < 0 || N < 0 || !sums || !partials || !status) return DM_E_INVALID_ARG;
+    if (N > 0 && (!pred_boxes || !tgt_boxes || !pair_b || !pair_q || !pair_t)) return DM_E_INVALID_ARG;
+    if (boxes_stride != 0 && (boxes_stride < Q * 4 || (boxes_stride & 3) != 0)) return DM_E_INVALID_ARG;
+    if (((reinterpret_cast<uintptr_t>(pred_boxes) | reinterpret_cast<uintptr_t>(tgt_boxes) |
+          reinterpret_cast<uintptr_t>(pair_grad)) & 15) != 0)
+        return DM_E_INVALID_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t image_rows = boxes_stride ? (size_t)(boxes_stride >> 2) : (size_t)Q;
+    const int64_t want = (N + PAIR_LIST_THREADS - 1) / PAIR_LIST_THREADS;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(PAIR_LIST_MAX_BLOCKS, want));
+    static_assert(2 * PAIR_LIST_MAX_BLOCKS <= DM_CLS_LOSS_PARTIALS, "the partial sums share the classification loss's workspace size");
+    hipLaunchKernelGGL(pair_list_loss_kernel, dim3(blocks), dim3(PAIR_LIST_THREADS), 0, st, pred_boxes, image_rows, B, Q, M,
+                       tgt_boxes, pair_b, pair_q, pair_t, N, pair_grad, partials, status);
+    int rc = dm::check_hip(hipGetLastError(), "pair_list_loss_kernel launch");
+    if (rc != DM_OK) return rc;
+    hipLaunchKernelGGL(pair_list_finish_kernel, dim3(1), dim3(64), 0, st, partials, blocks, sums);
+    return dm::check_hip(hipGetLastError(), "pair_list_finish_kernel launch");
+}
+
+extern "C" int dm_pair_list_backward_f32(const float *pair_grad, const float *grad_sums, const int64_t *pair_b,
+                                         const int64_t *pair_q, int64_t N, int B, int Q, float *grad_boxes, void *stream)
+{
+    if (B < 0 || Q < 1 || N < 0) return DM_E_INVALID_ARG;
+    if (N == 0) return DM_OK;
+    if (!pair_grad || !grad_sums || !pair_b || !pair_q || !grad_boxes) return DM_E_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(pair_grad) & 15) != 0) return DM_E_INVALID_ARG;
+    const int64_t want = (N + PAIR_LIST_THREADS - 1) / PAIR_LIST_THREADS;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(PAIR_LIST_MAX_BLOCKS, want));
+    hipLaunchKernelGGL(pair_list_backward_kernel, dim3(blocks), dim3(PAIR_LIST_THREADS), 0, static_cast<hipStream_t>(stream),
+                       pair_grad, grad_sums, pair_b, pair_q, N, B, Q, grad_boxes);
+    return dm::check_hip(hipGetLastError(), "pair_list_backward_kernel launch");
 }

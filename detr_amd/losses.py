@@ -134,6 +134,78 @@ def matched_box_loss_total(outputs_list, flats: Sequence[FlatMatches], l1_weight
     return (sums * scale).sum()
 
 
+class _PairListSums(torch.autograd.Function):
+    """[2] sums of |pred - target| and (1 - giou) over an explicit list of (image, query, packed target) pairs."""
+
+    @staticmethod
+    def forward(ctx, pred_boxes, tgt_boxes, pair_b, pair_q, pair_t):
+        device = pred_boxes.device
+        if pred_boxes.dtype != torch.float32 or pred_boxes.dim() != 3 or pred_boxes.shape[-1] != 4 or not pred_boxes.is_cuda:
+            raise ValueError("pred_boxes must be a float32 [B, Q, 4] tensor on a GPU")
+        if tgt_boxes.dtype != torch.float32 or tgt_boxes.dim() != 2 or tgt_boxes.shape[-1] != 4 or tgt_boxes.device != device:
+            raise ValueError("tgt_boxes must be a float32 [M, 4] tensor on the device of the predictions")
+        n = int(pair_b.shape[0])
+        for idx in (pair_b, pair_q, pair_t):
+            if idx.dtype != torch.int64 or idx.dim() != 1 or idx.shape[0] != n or idx.device != device:
+                raise ValueError("the pair indices must be int64 [N] tensors on the device of the predictions")
+        B, Q = int(pred_boxes.shape[0]), int(pred_boxes.shape[1])
+        p = pred_boxes.detach()
+        stride = ops.image_stride(p)
+        if stride is None or stride % 4 or p.data_ptr() % 16:
+            p = p.contiguous()
+            if p.data_ptr() % 16:
+                p = p.clone()
+            stride = 0
+        g = tgt_boxes.detach().contiguous()
+        if g.data_ptr() % 16:
+            g = g.clone()
+        pair_b, pair_q, pair_t = pair_b.contiguous(), pair_q.contiguous(), pair_t.contiguous()
+        sums = torch.empty(2, dtype=torch.float32, device=device)
+        want_grad = ctx.needs_input_grad[0]
+        pair_grad = torch.empty(max(n, 1), 8, dtype=torch.float32, device=device) if want_grad else None
+        with torch.cuda.device(device):
+            partials, status, stream = _cls_buffers(device)
+            rc = lib.dm_pair_list_loss_f32(p.data_ptr(), stride, B, Q, g.data_ptr(), int(g.shape[0]), pair_b.data_ptr(),
+                                           pair_q.data_ptr(), pair_t.data_ptr(), n, sums.data_ptr(),
+                                           pair_grad.data_ptr() if want_grad else None, partials.data_ptr(),
+                                           status.data_ptr(), stream)
+        _lib.check(rc, "dm_pair_list_loss_f32")
+        ctx.shape = pred_boxes.shape
+        if want_grad:
+            ctx.save_for_backward(pair_grad, pair_b, pair_q)
+        return sums
+
+    @staticmethod
+    def backward(ctx, grad_sums):
+        pair_grad, pair_b, pair_q = ctx.saved_tensors
+        device = pair_grad.device
+        grad = torch.zeros(ctx.shape, dtype=torch.float32, device=device)
+        gs = grad_sums.contiguous().to(torch.float32)
+        with torch.cuda.device(device):
+            # (a query may occur in several pairs: the kernel adds with float atomics)
+            rc = lib.dm_pair_list_backward_f32(pair_grad.data_ptr(), gs.data_ptr(), pair_b.data_ptr(), pair_q.data_ptr(),
+                                               int(pair_b.shape[0]), int(ctx.shape[0]), int(ctx.shape[1]), grad.data_ptr(),
+                                               torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(rc, "dm_pair_list_backward_f32")
+        return grad, None, None, None, None
+
+
+def pair_list_box_loss_sums(pred_boxes: torch.Tensor, tgt_boxes: torch.Tensor, pair_b: torch.Tensor, pair_q: torch.Tensor,
+                            pair_t: torch.Tensor) -> torch.Tensor:
+    """`[sum |pred - target|, sum (1 - giou)]` over the pairs (pred_boxes[pair_b[k], pair_q[k]], tgt_boxes[pair_t[k]]) --
+    the two sums of `calc_box_loss` (/root/reference/models/detr/loss.py:105-112 before the division by num_boxes) for
+    indices that did not come from the matcher: the denoising groups of DN-DETR / DINO / Co-DETR bring their own
+    (/root/reference/models/dino_detr/dino_func.py:117-124), where the reference's `[N, N]` GIoU matrix has N = groups x
+    targets of the whole batch.  O(N); a query may occur in several pairs (its gradients add up); an index out of range
+    is reported by `check_cls_status()`.  Differentiable in `pred_boxes`."""
+    return _PairListSums.apply(pred_boxes, tgt_boxes, pair_b, pair_q, pair_t)
+
+
+def _takes_boxes(pred_boxes) -> bool:
+    """Whether the pair kernels take these prediction boxes (anything else goes to the caller's own implementation)."""
+    return pred_boxes.is_cuda and pred_boxes.dtype == torch.float32 and pred_boxes.dim() == 3 and pred_boxes.shape[-1] == 4
+
+
 @torch.no_grad()
 def target_class_maps(flats: Sequence[FlatMatches], no_object: int) -> List[torch.Tensor]:
     """Dense `[B, Q]` int64 class map of every output set (loss.py:121-125), one launch."""
@@ -170,12 +242,14 @@ def _cls_buffers(device):
 def check_cls_status(device=None) -> None:
     """Raises RuntimeError when a `focal_loss` / `cross_entropy` call on `device` (default: the current one) since the
     last check met a class value outside the range the reference accepts (its `one_hot` / `cross_entropy` raise for
-    such a value at once; here the row counts as ignored and the finding waits for this call).  Synchronises."""
+    such a value at once; here the row counts as ignored and the finding waits for this call), or a
+    `pair_list_box_loss_sums` call met an index outside its tensor.  Synchronises."""
     index = torch.cuda.current_device() if device is None else torch.device(device).index
     status = _cls_status.get(index)
     if status is not None and int(status.item()):
         status.zero_()
-        raise RuntimeError("class values must lie in [0, number of classes] (the last one meaning no object)")
+        raise RuntimeError("class values must lie in [0, number of classes] (the last one meaning no object), "
+                           "pair indices inside their tensors")
 
 
 def _checked(logits, target_cls):

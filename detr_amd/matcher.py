@@ -514,8 +514,9 @@ class HungarianMatcher(torch.nn.Module):
         """Make `served_flat_of(indices_like)` answer `flat` until the prefetched results are dropped: for a consumer
         that hands a criterion an equivalent, cheaper stand-in for a served result (detr_amd.criterion)."""
         ahead = self.__dict__.get("_prefetched")
-        if ahead is not None:
-            ahead[("indices", id(indices_like))] = (indices_like, flat)
+        if ahead is None:
+            ahead = self.__dict__["_prefetched"] = {}
+        ahead[("indices", id(indices_like))] = (indices_like, flat)
 
     def served_flat(self, outputs, indices) -> Optional["FlatMatches"]:
         """The `FlatMatches` of `outputs` when `indices` is the very result `prefetch(..., flat=True)` has ready for that

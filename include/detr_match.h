@@ -260,6 +260,34 @@ int dm_pair_loss_backward_f32(const DmIndexSet *sets, int S, int B, int M, const
                               const float *grad_sums, void *stream);
 
 /*
+ * The same two sums for an explicit list of pairs -- indices that did not come from the matcher: the denoising groups
+ * of DN-DETR / DINO / Co-DETR bring their own (/root/reference/models/dino_detr/loss.py:170-172, built at
+ * dino_func.py:117-124: several groups of queries per target), an auxiliary assigner may pair one prediction with
+ * several targets.  The reference's calc_box_loss builds an [N, N] GIoU matrix for them too (loss.py:108-111), N being
+ * groups x targets of the whole batch.
+ *   pred_boxes  device [B, Q, 4], 16-byte aligned, image b at pred_boxes + b * boxes_stride floats (0 = Q * 4)
+ *   tgt_boxes   device [M, 4]: the packed targets
+ *   pair_b / pair_q / pair_t   device int64[N]: image, query and packed target of every pair
+ *   sums        device float[2]: sum |pred - target| and sum (1 - giou) (the caller divides by num_boxes)
+ *   pair_grad   device float[N][8] or NULL: d l1 / d pred (4) and d (1 - giou) / d pred (4) of every pair; the
+ *               caller accumulates them into [B, Q, 4] (a query may occur in several pairs)
+ *   partials    device double[DM_CLS_LOSS_PARTIALS] workspace;  status: DM_ST_LABEL_RANGE for an index out of range
+ *               (the reference's gathers raise IndexError; the pair contributes nothing)
+ */
+int dm_pair_list_loss_f32(const float *pred_boxes, int boxes_stride, int B, int Q, const float *tgt_boxes, int M,
+                          const int64_t *pair_b, const int64_t *pair_q, const int64_t *pair_t, int64_t N,
+                          float *sums, float *pair_grad, double *partials, int32_t *status, void *stream);
+
+/*
+ * Backward of dm_pair_list_loss_f32 (what autograd produces for loss.py:102-112 on such indices):
+ * grad_boxes[b][q] += grad_sums[0] * d l1 + grad_sums[1] * d (1 - giou) over the pairs of (b, q).
+ *   grad_sums   device float[2];  grad_boxes  device [B, Q, 4] contiguous, zeroed by the caller
+ * The additions are float atomics: a query that occurs in several pairs receives them in no fixed order.
+ */
+int dm_pair_list_backward_f32(const float *pair_grad, const float *grad_sums, const int64_t *pair_b,
+                              const int64_t *pair_q, int64_t N, int B, int Q, float *grad_boxes, void *stream);
+
+/*
  * Dense class map of every set: target_cls[b][q] = label of the target matched to query q, else
  * no_object (/root/reference/models/detr/loss.py:121-125).  Limit: Q <= 40960.
  */

@@ -95,8 +95,9 @@ def box_losses(pred_boxes, target_boxes, indices):
     giou_loss = (F(1) - giou).sum(dtype=F) / F(num_boxes)
     grad_l1 = np.zeros_like(pred_boxes)
     grad_giou = np.zeros_like(pred_boxes)
-    grad_l1[bi, si] = np.sign(diff) / F(num_boxes)
-    grad_giou[bi, si] = -ggrad / F(num_boxes)
+    # (accumulated: indices that did not come from the matcher may name a prediction in several pairs)
+    np.add.at(grad_l1, (bi, si), np.sign(diff) / F(num_boxes))
+    np.add.at(grad_giou, (bi, si), -ggrad / F(num_boxes))
     return F(l1), F(giou_loss), grad_l1, grad_giou
 
 

@@ -122,6 +122,30 @@ def cls_case_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(CLS_DIR, "*.npz")))
 
 
+PAIRS_DIR = os.path.join(GOLDEN_DIR, "pairs")
+
+
+class PairListCase:
+    """A golden case of tests/golden/pairs (made by gen_golden_pairs.py): prediction boxes, per-image target boxes and
+    per-image (query, target) index pairs that did not come from the matcher; the reference's l1 / giou loss and their
+    gradients w.r.t. the prediction boxes."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(PAIRS_DIR, name + ".npz"), allow_pickle=False)
+        self.name, self.pred_boxes = name, z["pred_boxes"]
+        t_off = np.concatenate([[0], np.cumsum(z["tsizes"])])
+        i_off = np.concatenate([[0], np.cumsum(z["isizes"])])
+        B = len(z["tsizes"])
+        self.target_boxes = [z["tboxes"][t_off[b]:t_off[b + 1]].reshape(-1, 4) for b in range(B)]
+        self.indices = [(z["src"][i_off[b]:i_off[b + 1]], z["tgt"][i_off[b]:i_off[b + 1]]) for b in range(B)]
+        self.l1, self.giou = float(z["l1"]), float(z["giou"])
+        self.grad_l1, self.grad_giou = z["grad_l1"], z["grad_giou"]
+
+
+def pair_case_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(PAIRS_DIR, "*.npz")))
+
+
 def dtype_case_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(DTYPE_DIR, "*.npz")))
 

@@ -291,7 +291,7 @@ def test_attach_with_the_fused_consumers():
         got = crit(outputs, targets)
     finally:
         losses.matched_box_losses = inner
-    assert len(calls) == 3                                   # the three matched sets; the denoising set took the own method
+    assert len(calls) == 3                                   # the three matched sets; the denoising set went by its list of pairs
     for (a, b), (wa, wb) in zip(crit.box_losses, want_losses):
         assert abs(a.item() - wa) <= 1e-5 * max(1.0, abs(wa)) and abs(b.item() - wb) <= 1e-5 * max(1.0, abs(wb))
     # the class maps come out of the criterion's own calc_cls_loss, handed the batch as one pseudo-image

@@ -388,3 +388,54 @@ def test_fused_consumers_front_co_detrs_loss_with_ignore(reference, aux_flag, mo
     detach(criterion)
     assert "calc_cls_loss_with_ignore" not in criterion.__dict__
     torch.testing.assert_close(criterion(outputs, targets), want, rtol=1e-6, atol=1e-6)
+
+
+class _PackedOnCpu:
+    """Stands where PackedTargets is when the tensors are on the CPU: the packed boxes / labels and the offsets."""
+
+    def __init__(self, targets, device):
+        self.sizes = [int(t["boxes"].shape[0]) for t in targets]
+        self.offsets_list = [0] + np.cumsum(self.sizes).tolist()
+        self.total, self.batch, self.device = self.offsets_list[-1], len(targets), device
+        self.boxes = torch.cat([t["boxes"].reshape(-1, 4) for t in targets])
+        self.labels = torch.cat([t["labels"] for t in targets])
+
+
+@pytest.mark.parametrize("cls_loss", ["ce", "focal"])
+@pytest.mark.parametrize("fam", ["dn_detr", "dino_detr", "co_detr"])
+def test_fused_consumers_take_the_denoising_groups_by_their_list_of_pairs(reference, fam, cls_loss, monkeypatch):
+    """The denoising groups bring their own indices and targets (dino_detr/loss.py:170-172): with fused_consumers=True
+    their box loss goes through the pair-list kernel (stood in for by stock torch ops on the three flat index tensors)
+    and their class loss through the criterion's own body on the pseudo-image -- total loss equal to the unmodified
+    criterion's, inside the reference's three real criteria that have such groups."""
+    import detr_amd.matcher as dm_matcher
+    from detr_amd import losses as dm_losses
+    from detr_amd.criterion import attach
+
+    matcher_mod, losses = reference
+    gen = torch.Generator().manual_seed(300 + FAMILIES.index(fam) * 2 + (cls_loss == "ce"))
+    outputs, targets, n_cls = _inputs(fam, cls_loss, gen)
+    criterion = losses[fam].Criterion(matcher=matcher_mod.HungarianMatcher(cls_loss, 2.0, 5.0, 2.0), n_cls=n_cls,
+                                      cls_loss=cls_loss)
+    want = criterion(outputs, targets)
+    matcher = attach(criterion, fused_consumers=True)
+    matcher.match_flat = _cpu_flat_stand_in(matcher, [])
+    matcher.check_status = lambda: None
+    list_calls = []
+
+    def pair_list_stand_in(pred, tgt_boxes, b, q, t):
+        list_calls.append(int(b.shape[0]))
+        one = types.SimpleNamespace(batch_idx=b, src_idx=q, tgt_flat=t, packed=types.SimpleNamespace(boxes=tgt_boxes))
+        l1, giou = _torch_pair_losses([{"pred_boxes": pred}], [one])[0]
+        return torch.stack([l1, giou]) * float(max(len(b), 1))
+
+    monkeypatch.setattr(dm_losses, "matched_box_losses", _torch_pair_losses)
+    monkeypatch.setattr(dm_losses, "pair_list_box_loss_sums", pair_list_stand_in)
+    monkeypatch.setattr(dm_losses, "_takes_boxes", lambda p: True)
+    monkeypatch.setattr(dm_losses, "check_cls_status", lambda device=None: None)
+    monkeypatch.setattr(dm_matcher, "PackedTargets", _PackedOnCpu)
+    got = criterion(outputs, targets)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    key = "noised" if fam == "dn_detr" else "cdn"
+    n_pairs = sum(len(s) for s, _ in outputs[key + "_indices"])
+    assert list_calls == [n_pairs] * len(outputs[key])            # every denoising set, and only those

@@ -103,7 +103,14 @@ class Criterion(torch.nn.Module):
             indices = self.matcher(output, targets)
             l1, giou = self.calc_box_loss(output, targets, indices)
             total = total + 5.0 * l1 + 2.0 * giou + 2.0 * self.calc_cls_loss(output, targets, indices)
-        return total / len(outputs["model"])
+        total = total / len(outputs["model"])
+        if "cdn" in outputs:            # the denoising groups bring their indices and targets (dino_detr/loss.py:170-172)
+            dn = 0.0
+            for output in outputs["cdn"]:
+                l1, giou = self.calc_box_loss(output, outputs["cdn_targets"], outputs["cdn_indices"])
+                dn = dn + 5.0 * l1 + 2.0 * giou + 2.0 * self.calc_cls_loss(output, outputs["cdn_targets"], outputs["cdn_indices"])
+            total = total + dn / len(outputs["cdn"])
+        return total
 
 
 class RewrittenCriterion(torch.nn.Module):
@@ -131,13 +138,39 @@ class RewrittenCriterion(torch.nn.Module):
         return total / len(per_set)
 
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+with_dn = "--dn" in sys.argv            # + denoising groups laid out as /root/reference/models/dino_detr/dino_func.py:57-129 does
+name = args[0] if args else "cfg2"
 wl, sets, targets = synth.make_workload(name, device="cuda")
 for o in sets:
     o["pred_boxes"].requires_grad_(True)
     o["pred_logits"].requires_grad_(True)
 outputs = {"model": sets}
 pool = [[{k: v[:] for k, v in t.items()} for t in targets] for _ in range(4)]
+if with_dn:
+    num_group, sizes = 5, [len(t["labels"]) for t in targets]
+    max_obj = max(sizes)
+    gen = torch.Generator().manual_seed(11)
+    dn_targets, dn_indices = [], []
+    for t, n in zip(targets, sizes):
+        boxes, labels = t["boxes"], t["labels"]
+        if 0 < n < max_obj:
+            extra = torch.randint(0, n, (max_obj - n,), generator=gen).cuda()
+            boxes, labels = torch.cat([boxes, boxes[extra]]), torch.cat([labels, labels[extra]])
+        if n:
+            boxes, labels = boxes.repeat(num_group, 1), labels.repeat(num_group)
+        dn_targets.append({"boxes": boxes.contiguous(), "labels": labels.contiguous()})
+        num_pos = max_obj if n else 0
+        idx = torch.arange(num_pos).unsqueeze(0).repeat(num_group, 1)
+        dn_indices.append(((idx + torch.arange(num_group).unsqueeze(1) * num_pos * 2).view(-1),
+                           (idx + torch.arange(num_group).unsqueeze(1) * num_pos).view(-1)))
+    q_dn = num_group * max_obj * 2
+    outputs["cdn"] = [{"pred_logits": (torch.randn(wl.batch, q_dn, wl.n_logits, generator=gen) * 2).cuda().requires_grad_(True),
+                       "pred_boxes": torch.cat([torch.rand(wl.batch, q_dn, 2, generator=gen),
+                                                torch.rand(wl.batch, q_dn, 2, generator=gen) * 0.3 + 0.01], -1).cuda().requires_grad_(True)}
+                      for _ in sets]
+    outputs["cdn_targets"], outputs["cdn_indices"] = dn_targets, dn_indices
+    print(f"+ denoising groups: {len(sets)} sets of {q_dn} queries, {sum(len(s) for s, _ in dn_indices)} pairs each")
 
 
 def timeit(criterion, n=30):
@@ -168,6 +201,8 @@ detach(crit)
 attach(crit, fused_consumers=True)
 print("  attach, fused consumers  %8.2f   %.6f" % timeit(crit))
 detach(crit)
+if with_dn:
+    sys.exit(0)
 new = RewrittenCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss).cuda()
 print("  forward on set_losses    %8.2f   %.6f" % timeit(new))
 new.one_scalar = True
