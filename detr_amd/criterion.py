@@ -138,7 +138,9 @@ def flat_of_foreign_indices(matcher: HungarianMatcher, outputs, targets, indices
             if s_.dtype != torch.int64 or t_.dtype != torch.int64 or s_.dim() != 1 or s_.shape != t_.shape \
                     or s_.device != srcs[0].device or t_.device != srcs[0].device:
                 return None
-        packed = PackedTargets(targets, pred.device)
+        packed = matcher.__dict__.get("_packed")          # (the step's own targets: packed by the matching call already)
+        if packed is None or packed.device != pred.device or not packed.same_targets(targets):
+            packed = PackedTargets(targets, pred.device)
     except (TypeError, ValueError, RuntimeError, KeyError, AttributeError):
         return None
     lens = np.asarray([int(s_.shape[0]) for s_ in srcs], dtype=np.int64)

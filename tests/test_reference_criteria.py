@@ -109,6 +109,8 @@ def _inputs(fam, cls_loss, gen):
 
 
 class _KnowsItsTargets:
+    device = torch.device("cpu")
+
     def __init__(self, targets):
         self.targets = targets
 
