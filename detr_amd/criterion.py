@@ -275,16 +275,30 @@ def attach(criterion: torch.nn.Module, keys: Sequence[str] = MATCHED_KEYS, aux_h
             if logits.dim() != 3 or logits.shape[-1] != n_cls \
                     or not losses._takes(logits, torch.empty(0, dtype=torch.int64, device=device)):
                 return own_with_ignore(outputs, targets, pos_indices, neg_indices)
-            pos_b = [torch.full_like(src, b) for b, (src, _) in enumerate(pos_indices)]
-            neg_b = [torch.full_like(src, b) for b, src in enumerate(neg_indices)]
-            pos_s, neg_s = [src for src, _ in pos_indices], list(neg_indices)
-            n_pos = sum(int(s.shape[0]) for s in pos_s)
+            n_pos = sum(int(src.shape[0]) for src, _ in pos_indices)
             target_cls = torch.full(logits.shape[:2], -1, dtype=torch.int64, device=device)
             if n_pos:
-                labels = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, pos_indices)])
-                target_cls[torch.cat(pos_b).to(device), torch.cat(pos_s).to(device)] = labels.to(device)
-            if sum(int(s.shape[0]) for s in neg_s):
-                target_cls[torch.cat(neg_b).to(device), torch.cat(neg_s).to(device)] = n_cls
+                # the positives as one (image, query, packed target) list -- the one calc_box_loss has just used for
+                # the same indices -- instead of a label gather and an index upload per image
+                m = criterion.matcher
+                flat = flat_of_foreign_indices(m, outputs, targets, pos_indices) if isinstance(m, HungarianMatcher) else None
+                if flat is not None:
+                    target_cls[flat.batch_idx, flat.src_idx] = flat.packed.labels[flat.tgt_flat]
+                else:
+                    pos_b = torch.cat([torch.full_like(src, b) for b, (src, _) in enumerate(pos_indices)])
+                    labels = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, pos_indices)])
+                    target_cls[pos_b.to(device), torch.cat([src for src, _ in pos_indices]).to(device)] = labels.to(device)
+            neg_s = list(neg_indices)
+            lens = np.asarray([int(src.shape[0]) for src in neg_s], dtype=np.int64)
+            if int(lens.sum()):
+                neg_q = torch.cat(neg_s)
+                neg_b = torch.from_numpy(np.repeat(np.arange(len(neg_s), dtype=np.int64), lens))
+                if neg_q.device.type == "cpu" and neg_q.dtype == torch.int64:
+                    both = torch.stack([neg_b, neg_q]).to(device)
+                    neg_b, neg_q = both[0], both[1]
+                else:
+                    neg_b, neg_q = neg_b.to(device), neg_q.to(device)
+                target_cls[neg_b, neg_q] = n_cls
             cls_devices.add(device)
             return losses.focal_loss(logits, target_cls, max(n_pos, 1), 0.25, 2.0, ignore_index=-1)
 

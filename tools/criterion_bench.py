@@ -97,6 +97,23 @@ class Criterion(torch.nn.Module):
         target_cls[idx] = torch.cat([t["labels"][j] for t, (_, j) in zip(targets, indices)])
         return self.cls_criterion(logits.transpose(1, 2), target_cls, n)
 
+    def calc_cls_loss_with_ignore(self, outputs, targets, pos_indices, neg_indices):      # co_detr/loss.py:143-167
+        logits = outputs["pred_logits"]
+        pidx = self._get_src_permutation_idx(pos_indices)
+        nidx = (torch.cat([torch.full_like(s, i) for i, s in enumerate(neg_indices)]), torch.cat(list(neg_indices)))
+        num_boxes = max(len(pidx[0]), 1)
+        target_cls = torch.full(logits.shape[:2], -1, device=logits.device)
+        target_cls[pidx] = torch.cat([t["labels"][i] for t, (_, i) in zip(targets, pos_indices)])
+        target_cls[nidx] = torch.cat([torch.full(i.shape, self.n_cls) for i in neg_indices]).to(logits.device)
+        fg = target_cls != -1
+        src, tgt = logits[fg], target_cls[fg]
+        onehot = F.one_hot(tgt, self.n_cls + 1)[..., :-1].float()
+        p = src.sigmoid()
+        ce = F.binary_cross_entropy_with_logits(src, onehot, reduction="none")
+        p_t = p * onehot + (1 - p) * (1 - onehot)
+        loss = (0.25 * onehot + 0.75 * (1 - onehot)) * ce * (1 - p_t) ** 2.0
+        return loss[None].mean(1).sum() / num_boxes * src.shape[0]
+
     def forward(self, outputs, targets):
         total = 0.0
         for output in outputs["model"]:
@@ -104,6 +121,20 @@ class Criterion(torch.nn.Module):
             l1, giou = self.calc_box_loss(output, targets, indices)
             total = total + 5.0 * l1 + 2.0 * giou + 2.0 * self.calc_cls_loss(output, targets, indices)
         total = total / len(outputs["model"])
+        if "aux" in outputs:            # Co-DETR's collaborative heads (co_detr/loss.py:222-241)
+            for key, head in self.aux_heads.items():
+                part = 0.0
+                for output in outputs["aux"][key]:
+                    if key == "atss":
+                        indices = head(output, targets)
+                        l1, giou = self.calc_box_loss(output, targets, indices)
+                        cls = self.calc_cls_loss(output, targets, indices)
+                    else:
+                        pos, neg = head(output, targets)
+                        l1, giou = self.calc_box_loss(output, targets, pos)
+                        cls = self.calc_cls_loss_with_ignore(output, targets, pos, neg)
+                    part = part + 5.0 * l1 + 2.0 * giou + 2.0 * cls
+                total = total + part / len(outputs["aux"][key])
         if "cdn" in outputs:            # the denoising groups bring their indices and targets (dino_detr/loss.py:170-172)
             dn = 0.0
             for output in outputs["cdn"]:
@@ -139,6 +170,7 @@ class RewrittenCriterion(torch.nn.Module):
 
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
+with_aux = "--aux" in sys.argv          # + Co-DETR's auxiliary heads (ATSS, Faster-RCNN style), focal workloads only
 with_dn = "--dn" in sys.argv            # + denoising groups laid out as /root/reference/models/dino_detr/dino_func.py:57-129 does
 name = args[0] if args else "cfg2"
 wl, sets, targets = synth.make_workload(name, device="cuda")
@@ -185,7 +217,25 @@ def timeit(criterion, n=30):
     return (time.perf_counter() - t0) / n * 1e3, float(loss.detach())
 
 
+if with_aux:
+    gen = torch.Generator().manual_seed(12)
+    aux_sets = {}
+    for key in ("atss", "faster_rcnn"):
+        aux_sets[key] = []
+        for o in sets:
+            boxes = o["pred_boxes"].detach().clone()
+            for b, t in enumerate(targets):          # some predictions close to the targets, as a trained head has
+                k = len(t["labels"])
+                boxes[b, :k] = (t["boxes"] + 0.003).clamp(0.01, 0.99)
+            aux_sets[key].append({"pred_logits": (torch.randn(o["pred_logits"].shape, generator=gen) * 2).cuda().requires_grad_(True),
+                                  "pred_boxes": boxes.requires_grad_(True)})
+    outputs["aux"] = aux_sets
+    print(f"+ auxiliary heads: ATSS(k=9) and Faster-RCNN on {len(sets)} sets each")
 crit = Criterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss).cuda()
+if with_aux:
+    from detr_amd import aux_assign
+
+    crit.aux_heads = {"atss": aux_assign.ATSS(9), "faster_rcnn": aux_assign.FasterRCNN()}
 print(f"{name}: criterion forward + backward per step (ms), loss value")
 print("  import swapped           %8.2f   %.6f" % timeit(crit))
 attach(crit)
@@ -201,7 +251,7 @@ detach(crit)
 attach(crit, fused_consumers=True)
 print("  attach, fused consumers  %8.2f   %.6f" % timeit(crit))
 detach(crit)
-if with_dn:
+if with_dn or with_aux:
     sys.exit(0)
 new = RewrittenCriterion(detr_amd.HungarianMatcher(**wl.matcher_kwargs), wl.n_label_classes, wl.cls_loss).cuda()
 print("  forward on set_losses    %8.2f   %.6f" % timeit(new))
