@@ -156,8 +156,9 @@ class FasterRCNN(torch.nn.Module):
                                packed, S)
         result = []
         for s in range(S):
-            Q = queries[s]
-            neg_indices = [torch.from_numpy(np.nonzero(neg[s, b, :Q])[0]) for b in range(B)]
+            # one scan of the set's [B, Q] table (row-major: ascending prediction index inside every image), split by image
+            b_idx, q_idx = np.nonzero(neg[s, :, :queries[s]])
+            neg_indices = list(torch.from_numpy(q_idx).split(np.bincount(b_idx, minlength=B).tolist()))
             result.append((pos[s], neg_indices))
         return result
 
