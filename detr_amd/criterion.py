@@ -151,7 +151,14 @@ def flat_of_foreign_indices(matcher: HungarianMatcher, outputs, targets, indices
     image = torch.from_numpy(np.repeat(np.arange(B, dtype=np.int64), lens))
     first = torch.from_numpy(np.repeat(np.asarray(packed.offsets_list[:-1], dtype=np.int64), lens))
     if srcs[0].device.type == "cpu":            # (the reference builds them with torch.arange on the host)
-        trio = torch.stack([image, torch.cat(srcs), torch.cat(tgts) + first]).to(pred.device)
+        query, local = torch.cat(srcs), torch.cat(tgts)
+        # torch's indexing also takes negative positions and raises for those beyond the end: such lists stay with
+        # the criterion's own code (checked here where it costs nothing; indices on the device are checked by the
+        # kernel against the batch-wide bounds only)
+        limit = torch.from_numpy(np.repeat(np.asarray(packed.sizes, dtype=np.int64), lens))
+        if bool((local < 0).any()) or bool((local >= limit).any()) or bool((query < 0).any()) or bool((query >= pred.shape[1]).any()):
+            return None
+        trio = torch.stack([image, query, local + first]).to(pred.device)
         image, query, slot = trio[0], trio[1], trio[2]
     else:
         image, query, slot = image.to(pred.device), torch.cat(srcs), torch.cat(tgts) + first.to(pred.device)

@@ -133,6 +133,10 @@ def test_what_is_not_a_list_of_index_pairs_is_left_to_the_caller():
     assert flat_of_foreign_indices(m, {"pred_boxes": pred.cpu()}, targets, [pair, pair]) is None       # CPU predictions
     assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [(pair[0].int(), pair[1].int())] * 2) is None
     assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [(pair[0], pair[1][:1])] * 2) is None
+    # a target position beyond the image's targets, or a negative (wrap-around) position: torch's own indexing decides
+    assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [(pair[0], torch.tensor([1, 2]))] * 2) is None
+    assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [(pair[0], torch.tensor([-1, 0]))] * 2) is None
+    assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [(torch.tensor([0, 5]), pair[1])] * 2) is None
     none = (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64))
     assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [none, none]) is None             # no pair at all
     assert flat_of_foreign_indices(m, {"pred_boxes": pred}, targets, [pair, pair]) is not None
